@@ -1,0 +1,114 @@
+/*
+ * liblsm_hip.so — C ABI of the MI355X (gfx950) hot path of the LSM speech pipeline.
+ *
+ * The reference (adelitoo/lsm-speech-classifier) is pure Python and has no FFI of its own; the
+ * seam this library sits behind is the set of Python call sites listed per function below
+ * (file:line under /root/reference).  INTEGRATION.md shows the ctypes binding a maintainer of
+ * the reference would add.
+ *
+ * Conventions
+ *   - every function returns 0 on success or a negative LSM_ERR_* code; lsm_last_error() gives
+ *     the thread-local message of the last failure on the calling thread;
+ *   - every pointer named *_dev / audio / db / spikes / *_out is DEVICE memory owned by the
+ *     caller (e.g. torch.Tensor.data_ptr()); tables named coefs / thr_* / key_ids and every
+ *     argument of lsm_reservoir_create are HOST memory, copied during the call;
+ *   - every launch function takes a hipStream_t as `void *stream` and is asynchronous on it;
+ *     none of them allocates, frees or synchronises (safe under hipGraph capture);
+ *   - the only device memory the library owns is inside an lsm_reservoir handle;
+ *   - no global mutable state: distinct handles/streams may be used from distinct threads.
+ */
+#ifndef LSM_HIP_H
+#define LSM_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LSM_OK 0
+#define LSM_ERR_ARG (-1)
+#define LSM_ERR_HIP (-2)
+#define LSM_ERR_NOMEM (-3)
+#define LSM_ERR_UNSUPPORTED (-4)
+
+int lsm_version(void);                 /* major*10000 + minor*100 + patch */
+const char *lsm_last_error(void);
+int lsm_device_count(void);
+
+/* ---- front end ------------------------------------------------------------------------- */
+
+/* Replaces gammatone.gtgram.gtgram(wave, fs, window_time, hop_time, channels, f_min) as called
+ * at create_dataset.py:51-58, plus the dB conversion of create_dataset.py:59.
+ *   audio   (n_clips, n_samples) float32, device
+ *   coefs   (n_filters, 10) float64, HOST-side values uploaded by the caller to DEVICE memory:
+ *           rows [A0, A11, A12, A13, A14, A2, B0, B1, B2, gain], low -> high centre frequency
+ *   spec_out (n_clips, n_filters, ncols) float64 or NULL: sqrt(mean of squared filter output)
+ *   db_out   (n_clips, n_filters, ncols) float64 or NULL: 20*log10(spec + 1e-9)
+ * nwin/hop are in samples (400/160 for the reference call), nwin <= 4*hop. */
+int lsm_gammatone_spec_f64(const float *audio, int n_clips, int n_samples, const double *coefs_dev,
+                           int n_filters, int nwin, int hop, int ncols, double *spec_out,
+                           double *db_out, void *stream);
+
+/* Replaces create_dataset.py:60 (apply_floor: max-80 dB floor), :62-78 (min-max normalise with
+ * eps 1e-8, flat input -> zeros, scipy zoom(order=1) to time_bins columns, crop), :81-98
+ * (hysteresis encoder) and :101-104 (row repeat), one clip per workgroup.
+ *   db      (n_clips, n_filters, ncols) device
+ *   thr_on  n_thr ON thresholds sorted DESCENDING, thr_off the matching `thr - gap` values, both
+ *           already rounded to the spectrogram dtype by the caller (HOST memory, <= 8 entries)
+ *   raster  (n_clips, n_filters*redundancy, time_bins*n_thr) uint8 or NULL
+ *   norm_out (n_clips, n_filters, time_bins) or NULL: the normalised, resized spectrogram */
+int lsm_spec_to_spikes_f64(const double *db, int n_clips, int n_filters, int ncols, int time_bins,
+                           int apply_floor, const double *thr_on, const double *thr_off, int n_thr,
+                           int redundancy, uint8_t *raster, double *norm_out, void *stream);
+int lsm_spec_to_spikes_f32(const float *db, int n_clips, int n_filters, int ncols, int time_bins,
+                           int apply_floor, const float *thr_on, const float *thr_off, int n_thr,
+                           int redundancy, uint8_t *raster, float *norm_out, void *stream);
+
+/* Replaces convert_spectrogram_to_spikes_hysteresis (create_dataset.py:81-98) on an already
+ * normalised spectrogram: spec (n_rows, n_bins) -> out (n_rows, n_bins*n_thr) uint8. */
+int lsm_encode_hysteresis_f64(const double *spec, int n_rows, int n_bins, const double *thr_on,
+                              const double *thr_off, int n_thr, uint8_t *out, void *stream);
+int lsm_encode_hysteresis_f32(const float *spec, int n_rows, int n_bins, const float *thr_on,
+                              const float *thr_off, int n_thr, uint8_t *out, void *stream);
+
+/* ---- reservoir ------------------------------------------------------------------------- */
+
+typedef struct lsm_reservoir lsm_reservoir;
+
+/* Replaces SNN(simulation_params=...) (extract_lsm_features.py:188): uploads one reservoir's
+ * wiring (built on the host per SPEC.md §2) to the current device.  All arrays are HOST memory.
+ *   csc_ptr (N+1), csc_post (nnz, ascending within a column), csc_w (nnz): synapses grouped by
+ *           PRESYNAPTIC neuron j;  leak (N);  in_tgt (n_channels, in_fanout) target neurons of
+ *           each input channel;  out_idx (n_out) strictly ascending output neurons. */
+int lsm_reservoir_create(lsm_reservoir **out, int num_neurons, int n_channels,
+                         const int32_t *csc_ptr, const int32_t *csc_post, const float *csc_w,
+                         const float *leak, const int32_t *in_tgt, int in_fanout, float w_in,
+                         const int32_t *out_idx, int n_out, float theta, int refractory,
+                         int burst_isi_max);
+int lsm_reservoir_destroy(lsm_reservoir *h);
+
+/* Replaces, for a whole batch, the per-clip loop body of extract_all_features
+ * (extract_lsm_features.py:78-87): reset -> set_input_spike_times -> simulate ->
+ * extract_features_from_spikes -> nan_to_num -> concatenate in key order.
+ *   spikes_u8   (n_clips, n_channels, n_steps) uint8, device (File-1 layout, create_dataset.py:168)
+ *   key_ids     n_keys entries (HOST) from {0 spike_counts, 1 spike_variances, 2 mean_spike_times,
+ *               3 first_spike_times, 4 last_spike_times, 5 mean_isi, 6 isi_variances,
+ *               7 burst_counts} (FEATURE_SETS, extract_lsm_features.py:19-28)
+ *   features_out     (n_clips, n_keys*n_out) float32, device
+ *   spike_matrix_out (n_clips, n_steps, N) uint8 or NULL   (lsm.spike_matrix, :113-116)
+ *   v_trace_out      (n_clips, n_steps, N) float32 or NULL (membrane potential after each step)
+ *   waves_per_clip   0 = choose from the batch size; else 1, 2, 4, 8 or 16 */
+int lsm_reservoir_run(const lsm_reservoir *h, const uint8_t *spikes_u8, int n_clips, int n_steps,
+                      const int32_t *key_ids, int n_keys, float *features_out,
+                      uint8_t *spike_matrix_out, float *v_trace_out, int waves_per_clip,
+                      void *stream);
+
+/* Layout that lsm_reservoir_run would use: waves per clip, 64-neuron slots per lane, LDS bytes. */
+int lsm_reservoir_layout(const lsm_reservoir *h, int n_clips, int n_steps, int waves_per_clip,
+                         int *wpc_out, int *slots_out, int *lds_bytes_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LSM_HIP_H */

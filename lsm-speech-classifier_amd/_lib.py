@@ -1,0 +1,79 @@
+"""ctypes binding of liblsm_hip.so (include/lsm_hip.h).  There is no CPU fallback: if the
+library is missing or a call fails, this module raises."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+from . import build as _build
+
+_lib = None
+
+c_void = C.c_void_p
+c_int = C.c_int
+c_float = C.c_float
+
+_SIGS = {
+    "lsm_version": (c_int, []),
+    "lsm_last_error": (C.c_char_p, []),
+    "lsm_device_count": (c_int, []),
+    "lsm_gammatone_spec_f64": (c_int, [c_void, c_int, c_int, c_void, c_int, c_int, c_int, c_int,
+                                       c_void, c_void, c_void]),
+    "lsm_spec_to_spikes_f64": (c_int, [c_void, c_int, c_int, c_int, c_int, c_int, c_void, c_void,
+                                       c_int, c_int, c_void, c_void, c_void]),
+    "lsm_spec_to_spikes_f32": (c_int, [c_void, c_int, c_int, c_int, c_int, c_int, c_void, c_void,
+                                       c_int, c_int, c_void, c_void, c_void]),
+    "lsm_encode_hysteresis_f64": (c_int, [c_void, c_int, c_int, c_void, c_void, c_int, c_void, c_void]),
+    "lsm_encode_hysteresis_f32": (c_int, [c_void, c_int, c_int, c_void, c_void, c_int, c_void, c_void]),
+    "lsm_reservoir_create": (c_int, [C.POINTER(c_void), c_int, c_int, c_void, c_void, c_void, c_void,
+                                     c_void, c_int, c_float, c_void, c_int, c_float, c_int, c_int]),
+    "lsm_reservoir_destroy": (c_int, [c_void]),
+    "lsm_reservoir_run": (c_int, [c_void, c_void, c_int, c_int, c_void, c_int, c_void, c_void,
+                                  c_void, c_int, c_void]),
+    "lsm_reservoir_layout": (c_int, [c_void, c_int, c_int, c_int, C.POINTER(c_int),
+                                     C.POINTER(c_int), C.POINTER(c_int)]),
+}
+
+EXPORTED_SYMBOLS = tuple(_SIGS)
+
+
+class LsmHipError(RuntimeError):
+    pass
+
+
+def load():
+    """Load (once) and return the ctypes handle.  Raises LsmHipError when the library is absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    # torch ships its own libamdhip64 (same SONAME as /opt/rocm's).  Import it first so that this
+    # library binds to the runtime torch already initialised: two HIP runtimes in one process
+    # leave the second one without devices.
+    import torch  # noqa: F401
+    path = _build.lib_path()
+    if not os.path.exists(path):
+        raise LsmHipError(
+            f"{path} not found: the HIP extension is not built. Run `python -c \"import "
+            f"__graft_entry__ as g; g.build()\"` (needs hipcc). There is no CPU fallback.")
+    lib = C.CDLL(path)
+    for name, (res, args) in _SIGS.items():
+        fn = getattr(lib, name)          # AttributeError here = header/library mismatch
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str = "") -> None:
+    if rc != 0:
+        msg = load().lsm_last_error().decode("utf-8", "replace")
+        raise LsmHipError(f"{what or 'liblsm_hip call'} failed ({rc}): {msg}")
+
+
+def require_gpu() -> int:
+    """Number of HIP devices; raises when there is none (the product path never runs on CPU)."""
+    n = load().lsm_device_count()
+    if n <= 0:
+        msg = load().lsm_last_error().decode("utf-8", "replace")
+        raise LsmHipError(f"no HIP device visible ({n}): {msg}")
+    return n

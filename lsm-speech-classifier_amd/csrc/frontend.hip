@@ -1,0 +1,354 @@
+// Front end for gfx950: gammatone filterbank -> dB -> min-max normalise -> linear resize ->
+// hysteresis spike encoder (SPEC.md §1).
+//
+// Replaces /root/reference/create_dataset.py:49-60 (gammatone branch of audio_to_spectrogram,
+// arithmetic in gammatone==1.0.3 / scipy.signal.lfilter), :62-78 (normalise, zoom, crop),
+// :81-98 (convert_spectrogram_to_spikes_hysteresis) and :101-104 (create_pure_redundancy),
+// batched over clips.  Every float operation is written in the reference's order and compiled
+// with -ffp-contract=off so that results equal the CPU oracle bit for bit (log10 excepted: no
+// two libms agree on its last bit).
+#include "lsm_common.h"
+
+namespace {
+
+// ---------------------------------------------------------------------------------------------
+// Gammatone spectrogram.  One lane = one (clip, channel): four cascaded second-order sections in
+// float64 evaluated like scipy.signal.lfilter (direct form II transposed), / gain, squared, then
+// per column the sequential ascending sum of nwin samples, / nwin, sqrt.  Up to NWIN_MAX
+// overlapping windows are live at once (nwin <= NWIN_MAX * hop); they sit in named registers
+// that shift by one at every hop boundary.  Serial in time, parallel over clips x channels:
+// bound by float64 VALU issue, not by memory (64 KB of audio per clip, read through L1/L2).
+// ---------------------------------------------------------------------------------------------
+constexpr int NWIN_MAX = 4;
+
+__global__ __launch_bounds__(64) void gammatone_kernel(
+    const float *__restrict__ audio, int n_clips, int n_samples, const double *__restrict__ coefs,
+    int n_filters, int nwin, int hop, int ncols, double *__restrict__ spec_out,
+    double *__restrict__ db_out)
+{
+    const long g = (long)blockIdx.x * 64 + threadIdx.x;
+    if (g >= (long)n_clips * n_filters) return;
+    const int b = (int)(g / n_filters);
+    const int ch = (int)(g - (long)b * n_filters);
+    const double *k = coefs + (size_t)ch * 10;
+    const double a0 = k[6];
+    const double b0 = k[0] / a0, b2 = k[5] / a0;
+    const double b11 = k[1] / a0, b12 = k[2] / a0, b13 = k[3] / a0, b14 = k[4] / a0;
+    const double a1 = k[7] / a0, a2 = k[8] / a0, gain = k[9];
+    const float *x = audio + (size_t)b * n_samples;
+
+    double z01 = 0, z11 = 0, z02 = 0, z12 = 0, z03 = 0, z13 = 0, z04 = 0, z14 = 0;
+    double win[NWIN_MAX];
+#pragma unroll
+    for (int q = 0; q < NWIN_MAX; ++q) win[q] = 0.0;
+
+    const int n_end = (ncols - 1) * hop + nwin;          // samples past this feed no column
+    const int n_blocks = (n_end + hop - 1) / hop;
+    const double dn = (double)nwin;
+    for (int h = 0; h < n_blocks; ++h) {
+        // age q window started at block h - q and has nwin - q*hop samples left in this block
+        int len[NWIN_MAX];
+#pragma unroll
+        for (int q = 0; q < NWIN_MAX; ++q) {
+            const int left = nwin - q * hop;
+            len[q] = left < 0 ? 0 : (left < hop ? left : hop);
+        }
+        const int base = h * hop;
+        const int lim = (n_end - base) < hop ? (n_end - base) : hop;
+        for (int i = 0; i < lim; ++i) {
+            const double x0 = (double)x[base + i];
+            const double y1 = z01 + b0 * x0;
+            z01 = (z11 + x0 * b11) - y1 * a1;
+            z11 = x0 * b2 - y1 * a2;
+            const double y2 = z02 + b0 * y1;
+            z02 = (z12 + y1 * b12) - y2 * a1;
+            z12 = y1 * b2 - y2 * a2;
+            const double y3 = z03 + b0 * y2;
+            z03 = (z13 + y2 * b13) - y3 * a1;
+            z13 = y2 * b2 - y3 * a2;
+            const double y4 = z04 + b0 * y3;
+            z04 = (z14 + y3 * b14) - y4 * a1;
+            z14 = y3 * b2 - y4 * a2;
+            const double o = y4 / gain;
+            const double e = o * o;
+#pragma unroll
+            for (int q = 0; q < NWIN_MAX; ++q)
+                if (i < len[q]) win[q] += e;
+        }
+        // windows that ended inside this block: age q ends here iff 0 < nwin - q*hop <= hop
+#pragma unroll
+        for (int q = 0; q < NWIN_MAX; ++q) {
+            const int left = nwin - q * hop;
+            const int c = h - q;
+            if (left > 0 && left <= hop && c >= 0 && c < ncols) {
+                const double y = sqrt(win[q] / dn);
+                const size_t o = ((size_t)b * n_filters + ch) * ncols + c;
+                if (spec_out) spec_out[o] = y;
+                if (db_out) db_out[o] = 20 * log10(y + 1e-9);
+            }
+        }
+#pragma unroll
+        for (int q = NWIN_MAX - 1; q > 0; --q) win[q] = win[q - 1];
+        win[0] = 0.0;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Per clip: floor (optional) -> min/max -> normalise -> linear resize to time_bins -> hysteresis
+// encoder -> uint8 raster (n_filters*redundancy, time_bins*n_thr), staged in LDS and written out
+// with coalesced 4-byte stores.  One workgroup of 256 threads per clip; a thread owns a channel
+// for the serial part (time_bins x n_thr latch updates).
+// ---------------------------------------------------------------------------------------------
+template <typename T> struct Acc;          // arithmetic type of the normalise step per input dtype
+template <> struct Acc<double> { typedef double type; };
+template <> struct Acc<float> { typedef float type; };
+
+constexpr int MAX_THR = 8;
+
+template <typename T>
+struct SpikeArgs {
+    const T *db;            // (B, F, ncols)
+    int n_clips, n_filters, ncols, time_bins, apply_floor, n_thr, redundancy;
+    T on[MAX_THR], off[MAX_THR];
+    uint8_t *raster;        // (B, F*redundancy, time_bins*n_thr) or null
+    T *norm_out;            // (B, F, time_bins) or null
+};
+
+template <typename T>
+__device__ __forceinline__ T block_reduce(T v, bool is_max, T *scratch)
+{
+    for (int off = 32; off > 0; off >>= 1) {
+        const T o = __shfl_xor(v, off);
+        v = is_max ? (o > v ? o : v) : (o < v ? o : v);
+    }
+    const int w = threadIdx.x >> 6;
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) scratch[w] = v;
+    __syncthreads();
+    T r = scratch[0];
+    for (int i = 1; i < (int)(blockDim.x >> 6); ++i)
+        r = is_max ? (scratch[i] > r ? scratch[i] : r) : (scratch[i] < r ? scratch[i] : r);
+    return r;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void spec_to_spikes_kernel(const SpikeArgs<T> a)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    T *scratch = reinterpret_cast<T *>(smem);                 // 8 entries
+    uint8_t *stage = smem + 64;                               // F * time_bins * n_thr bytes
+    const int b = blockIdx.x;
+    const int F = a.n_filters, nc = a.ncols, Tb = a.time_bins;
+    const T *db = a.db + (size_t)b * F * nc;
+    const int n = F * nc;
+
+    T mx = -INFINITY, mn = INFINITY;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+        const T v = db[i];
+        mx = v > mx ? v : mx;
+        mn = v < mn ? v : mn;
+    }
+    mx = block_reduce(mx, true, scratch);
+    mn = block_reduce(mn, false, scratch);
+    // create_dataset.py:60 floors at max-80 before the min is taken: min' = max(min, max-80)
+    const T fl = a.apply_floor ? mx - (T)80.0 : -INFINITY;
+    const T lo = mn > fl ? mn : fl;
+    const T hi = mx;
+    const bool flat = (hi - lo) < (T)1e-8;
+    const T den = (hi - lo) + (T)1e-8;
+    const int row_bytes = Tb * a.n_thr;
+    const double zf = (double)(nc - 1) / (double)(Tb - 1);
+
+    for (int r = threadIdx.x; r < F; r += blockDim.x) {
+        const T *row = db + (size_t)r * nc;
+        bool active[MAX_THR];
+#pragma unroll
+        for (int q = 0; q < MAX_THR; ++q) active[q] = false;
+        for (int j = 0; j < Tb; ++j) {
+            T val;
+            if (flat) {
+                val = (T)0;
+            } else if (nc == Tb) {
+                T x0 = row[j];
+                x0 = x0 > fl ? x0 : fl;
+                val = (x0 - lo) / den;
+            } else {
+                // scipy.ndimage.zoom(order=1): double coordinate and weights, w1 = 1 - w0
+                const double cc = (double)j * zf;
+                const double fc = floor(cc);
+                const int f = (int)fc;
+                const double w0 = 1.0 - (cc - fc);
+                const double w1 = 1.0 - w0;
+                T x0 = row[f];
+                x0 = x0 > fl ? x0 : fl;
+                const T n0 = (x0 - lo) / den;
+                double acc = (double)n0 * w0;
+                if (f + 1 <= nc - 1) {
+                    T x1 = row[f + 1];
+                    x1 = x1 > fl ? x1 : fl;
+                    const T n1 = (x1 - lo) / den;
+                    acc = acc + (double)n1 * w1;
+                }
+                val = (T)acc;
+            }
+            if (a.norm_out) a.norm_out[((size_t)b * F + r) * Tb + j] = val;
+#pragma unroll
+            for (int q = 0; q < MAX_THR; ++q) {
+                if (q < a.n_thr) {
+                    const bool rising = (val > a.on[q]) && !active[q];
+                    const bool falling = (val < a.off[q]) && active[q];
+                    if (rising) active[q] = true;
+                    if (falling) active[q] = false;
+                    stage[(size_t)r * row_bytes + j * a.n_thr + q] = active[q] ? 1 : 0;
+                }
+            }
+        }
+    }
+    __syncthreads();
+    if (a.raster) {
+        // create_pure_redundancy: output row c reads filter row c / redundancy
+        const int C = F * a.redundancy;
+        uint8_t *dst = a.raster + (size_t)b * C * row_bytes;
+        if ((row_bytes & 3) == 0) {
+            const int rw = row_bytes / 4;
+            const uint32_t *s4 = reinterpret_cast<const uint32_t *>(stage);
+            uint32_t *d4 = reinterpret_cast<uint32_t *>(dst);
+            for (int i = threadIdx.x; i < C * rw; i += blockDim.x) {
+                const int c = i / rw;
+                d4[i] = s4[(c / a.redundancy) * rw + (i - c * rw)];
+            }
+        } else {
+            for (int i = threadIdx.x; i < C * row_bytes; i += blockDim.x) {
+                const int c = i / row_bytes;
+                dst[i] = stage[(size_t)(c / a.redundancy) * row_bytes + (i - c * row_bytes)];
+            }
+        }
+    }
+}
+
+// Stand-alone encoder on an already normalised spectrogram (B, F, n_bins): one lane per channel.
+template <typename T>
+__global__ __launch_bounds__(64) void encode_kernel(const T *__restrict__ spec, int n_rows,
+                                                    int n_bins, int n_thr, SpikeArgs<T> thr,
+                                                    uint8_t *__restrict__ out)
+{
+    const int r = blockIdx.x * 64 + threadIdx.x;
+    if (r >= n_rows) return;
+    const T *row = spec + (size_t)r * n_bins;
+    uint8_t *o = out + (size_t)r * n_bins * n_thr;
+    bool active[MAX_THR];
+#pragma unroll
+    for (int q = 0; q < MAX_THR; ++q) active[q] = false;
+    for (int j = 0; j < n_bins; ++j) {
+        const T val = row[j];
+#pragma unroll
+        for (int q = 0; q < MAX_THR; ++q) {
+            if (q < n_thr) {
+                const bool rising = (val > thr.on[q]) && !active[q];
+                const bool falling = (val < thr.off[q]) && active[q];
+                if (rising) active[q] = true;
+                if (falling) active[q] = false;
+                o[j * n_thr + q] = active[q] ? 1 : 0;
+            }
+        }
+    }
+}
+
+template <typename T>
+int launch_spec_to_spikes(const T *db, int n_clips, int n_filters, int ncols, int time_bins,
+                          int apply_floor, const T *thr_on, const T *thr_off, int n_thr,
+                          int redundancy, uint8_t *raster, T *norm_out, void *stream)
+{
+    LSM_REQUIRE(db != nullptr, "spec_to_spikes: null input");
+    LSM_REQUIRE(n_clips >= 0 && n_filters >= 1 && ncols >= 2 && time_bins >= 2, "bad shape");
+    LSM_REQUIRE(n_thr >= 0 && n_thr <= MAX_THR, "n_thr=%d outside [0, %d]", n_thr, MAX_THR);
+    LSM_REQUIRE(redundancy >= 1, "redundancy must be >= 1");
+    LSM_REQUIRE(n_thr == 0 || (thr_on && thr_off), "null threshold table");
+    LSM_REQUIRE(raster == nullptr || n_thr >= 1, "a raster needs at least one threshold");
+    if (n_clips == 0) return LSM_OK;
+    SpikeArgs<T> a;
+    a.db = db; a.n_clips = n_clips; a.n_filters = n_filters; a.ncols = ncols;
+    a.time_bins = time_bins; a.apply_floor = apply_floor; a.n_thr = n_thr;
+    a.redundancy = redundancy; a.raster = raster; a.norm_out = norm_out;
+    for (int q = 0; q < MAX_THR; ++q) { a.on[q] = q < n_thr ? thr_on[q] : (T)0; a.off[q] = q < n_thr ? thr_off[q] : (T)0; }
+    const size_t lds = 64 + (size_t)n_filters * time_bins * (n_thr > 0 ? n_thr : 1);
+    LSM_REQUIRE(lds <= 160 * 1024, "raster stage of %zu bytes exceeds one CU's LDS", lds);
+    auto fn = spec_to_spikes_kernel<T>;
+    if (lds > 64 * 1024)
+        LSM_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(fn),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(fn, dim3(n_clips), dim3(256), lds, (hipStream_t)stream, a);
+    LSM_CHECK_HIP(hipGetLastError());
+    return LSM_OK;
+}
+
+template <typename T>
+int launch_encode(const T *spec, int n_rows, int n_bins, const T *thr_on, const T *thr_off,
+                  int n_thr, uint8_t *out, void *stream)
+{
+    LSM_REQUIRE(spec && out && thr_on && thr_off, "encode: null buffer");
+    LSM_REQUIRE(n_rows >= 0 && n_bins >= 1 && n_thr >= 1 && n_thr <= MAX_THR, "bad shape");
+    if (n_rows == 0) return LSM_OK;
+    SpikeArgs<T> a{};
+    for (int q = 0; q < MAX_THR; ++q) { a.on[q] = q < n_thr ? thr_on[q] : (T)0; a.off[q] = q < n_thr ? thr_off[q] : (T)0; }
+    hipLaunchKernelGGL(encode_kernel<T>, dim3((n_rows + 63) / 64), dim3(64), 0, (hipStream_t)stream,
+                       spec, n_rows, n_bins, n_thr, a, out);
+    LSM_CHECK_HIP(hipGetLastError());
+    return LSM_OK;
+}
+
+}  // namespace
+
+#define LSM_API extern "C" __attribute__((visibility("default")))
+
+LSM_API int lsm_gammatone_spec_f64(const float *audio, int n_clips, int n_samples,
+                                   const double *coefs, int n_filters, int nwin, int hop,
+                                   int ncols, double *spec_out, double *db_out, void *stream)
+{
+    LSM_REQUIRE(audio && coefs, "gammatone: null input");
+    LSM_REQUIRE(spec_out || db_out, "gammatone: both outputs null");
+    LSM_REQUIRE(n_clips >= 0 && n_filters >= 1 && n_samples >= 1, "bad shape");
+    LSM_REQUIRE(nwin >= 1 && hop >= 1 && ncols >= 1, "bad window");
+    LSM_REQUIRE(nwin <= NWIN_MAX * hop, "nwin=%d needs more than %d overlapping windows of hop=%d",
+                nwin, NWIN_MAX, hop);
+    LSM_REQUIRE((long)(ncols - 1) * hop + nwin <= n_samples, "columns exceed the clip");
+    if (n_clips == 0) return LSM_OK;
+    const long lanes = (long)n_clips * n_filters;
+    hipLaunchKernelGGL(gammatone_kernel, dim3((unsigned)((lanes + 63) / 64)), dim3(64), 0,
+                       (hipStream_t)stream, audio, n_clips, n_samples, coefs, n_filters, nwin, hop,
+                       ncols, spec_out, db_out);
+    LSM_CHECK_HIP(hipGetLastError());
+    return LSM_OK;
+}
+
+LSM_API int lsm_spec_to_spikes_f64(const double *db, int n_clips, int n_filters, int ncols,
+                                   int time_bins, int apply_floor, const double *thr_on,
+                                   const double *thr_off, int n_thr, int redundancy,
+                                   uint8_t *raster, double *norm_out, void *stream)
+{
+    return launch_spec_to_spikes<double>(db, n_clips, n_filters, ncols, time_bins, apply_floor,
+                                         thr_on, thr_off, n_thr, redundancy, raster, norm_out, stream);
+}
+
+LSM_API int lsm_spec_to_spikes_f32(const float *db, int n_clips, int n_filters, int ncols,
+                                   int time_bins, int apply_floor, const float *thr_on,
+                                   const float *thr_off, int n_thr, int redundancy,
+                                   uint8_t *raster, float *norm_out, void *stream)
+{
+    return launch_spec_to_spikes<float>(db, n_clips, n_filters, ncols, time_bins, apply_floor,
+                                        thr_on, thr_off, n_thr, redundancy, raster, norm_out, stream);
+}
+
+LSM_API int lsm_encode_hysteresis_f64(const double *spec, int n_rows, int n_bins,
+                                      const double *thr_on, const double *thr_off, int n_thr,
+                                      uint8_t *out, void *stream)
+{
+    return launch_encode<double>(spec, n_rows, n_bins, thr_on, thr_off, n_thr, out, stream);
+}
+
+LSM_API int lsm_encode_hysteresis_f32(const float *spec, int n_rows, int n_bins,
+                                      const float *thr_on, const float *thr_off, int n_thr,
+                                      uint8_t *out, void *stream)
+{
+    return launch_encode<float>(spec, n_rows, n_bins, thr_on, thr_off, n_thr, out, stream);
+}

@@ -1,0 +1,34 @@
+// Shared declarations for the HIP translation units of liblsm_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#define LSM_WAVE 64
+
+// Error codes of the C ABI (include/lsm_hip.h).
+#define LSM_OK 0
+#define LSM_ERR_ARG -1
+#define LSM_ERR_HIP -2
+#define LSM_ERR_NOMEM -3
+#define LSM_ERR_UNSUPPORTED -4
+
+void lsm_set_error(const char *fmt, ...);
+
+#define LSM_CHECK_HIP(expr)                                                         \
+    do {                                                                            \
+        hipError_t _e = (expr);                                                     \
+        if (_e != hipSuccess) {                                                     \
+            lsm_set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e),    \
+                          __FILE__, __LINE__);                                      \
+            return LSM_ERR_HIP;                                                     \
+        }                                                                           \
+    } while (0)
+
+#define LSM_REQUIRE(cond, ...)                                                      \
+    do {                                                                            \
+        if (!(cond)) {                                                              \
+            lsm_set_error(__VA_ARGS__);                                             \
+            return LSM_ERR_ARG;                                                     \
+        }                                                                           \
+    } while (0)

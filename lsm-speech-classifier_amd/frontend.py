@@ -1,0 +1,227 @@
+"""Host mirror of the reference's front end (/root/reference/create_dataset.py:39-104) over the
+HIP kernels: same function names, argument meaning and defaults; batched variants underneath.
+
+Host code here only builds small parameter tables (filter coefficients, thresholds) and moves
+pointers; all per-sample arithmetic runs in liblsm_hip.so.  No CPU fallback exists.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib
+
+# create_dataset.py:10-17
+SAMPLE_RATE = 16000
+DURATION = 1.0
+TIME_BINS = 100
+SPIKE_THRESHOLDS = [0.70, 0.80, 0.90, 0.95]
+HYSTERESIS_GAP = 0.1
+REDUNDANCY_FACTOR = 1
+# gtgram call at create_dataset.py:51-58
+GT_WINDOW_TIME = 0.025
+GT_F_MIN = 50
+
+_EAR_Q = 9.26449          # Glasberg & Moore
+_MIN_BW = 24.7
+
+
+def gammatone_filter_table(fs: float, channels: int, f_min: float) -> np.ndarray:
+    """(channels, 10) float64 rows [A0, A11, A12, A13, A14, A2, B0, B1, B2, gain], ordered from
+    the lowest to the highest centre frequency: Slaney's ERB filterbank design (Apple TR #35) on
+    ERB-spaced centre frequencies between f_min and fs/2, as gammatone==1.0.3 computes it for
+    gtgram (the package itself is not available; SPEC.md §1.1)."""
+    frac = np.arange(1, channels + 1) / channels
+    c = _EAR_Q * _MIN_BW
+    high = fs / 2
+    cf = -c + np.exp(frac * (np.log(f_min + c) - np.log(high + c))) * (high + c)
+    cf = cf[::-1].copy()
+    T = 1.0 / fs
+    B = 1.019 * 2 * np.pi * (cf / _EAR_Q + _MIN_BW)
+    arg = 2 * cf * np.pi * T
+    ebt = np.exp(B * T)
+    vec = np.exp(2j * arg)
+    rt_pos, rt_neg = np.sqrt(3 + 2 ** 1.5), np.sqrt(3 - 2 ** 1.5)
+    common = -T * np.exp(-(B * T))
+    ks = [np.cos(arg) + rt_pos * np.sin(arg), np.cos(arg) - rt_pos * np.sin(arg),
+          np.cos(arg) + rt_neg * np.sin(arg), np.cos(arg) - rt_neg * np.sin(arg)]
+    gain_arg = np.exp(1j * arg - B * T)
+    gain = np.abs((vec - gain_arg * ks[0]) * (vec - gain_arg * ks[1]) * (vec - gain_arg * ks[2])
+                  * (vec - gain_arg * ks[3]) * (T * ebt / (-1 / ebt + 1 + vec * (1 - ebt))) ** 4)
+    tab = np.empty((channels, 10), dtype=np.float64)
+    tab[:, 0] = T
+    for q in range(4):
+        tab[:, 1 + q] = common * ks[q]
+    tab[:, 5] = 0.0
+    tab[:, 6] = 1.0
+    tab[:, 7] = -2 * np.cos(arg) / ebt
+    tab[:, 8] = np.exp(-2 * B * T)
+    tab[:, 9] = gain
+    return tab
+
+
+def _round_half_away(x: float) -> int:
+    return int(np.sign(x) * np.floor(np.abs(x) + 0.5))
+
+
+def gtgram_strides(fs: float, window_time: float, hop_time: float, n_samples: int):
+    nwin = _round_half_away(window_time * fs)
+    hop = _round_half_away(hop_time * fs)
+    return nwin, hop, 1 + int(np.floor((n_samples - nwin) / hop))
+
+
+def threshold_tables(thresholds, gap: float, dtype):
+    """ON thresholds sorted descending and the Python-float ``thr - gap`` OFF bounds
+    (create_dataset.py:87-89), rounded to the spectrogram dtype the comparison happens in."""
+    thr = sorted(thresholds, reverse=True)
+    on = np.array([dtype(t) for t in thr], dtype=dtype)
+    off = np.array([dtype(t - gap) for t in thr], dtype=dtype)
+    return on, off
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _dev(t: torch.Tensor) -> C.c_void_p:
+    return C.c_void_p(t.data_ptr())
+
+
+def _host(a: np.ndarray) -> C.c_void_p:
+    return C.c_void_p(a.ctypes.data)
+
+
+class SpikeFrontEnd:
+    """Batched filterbank -> dB -> normalise -> resize -> hysteresis encoder on one GPU."""
+
+    def __init__(self, n_filters: int, filterbank: str = "gammatone", device=None,
+                 redundancy: int = REDUNDANCY_FACTOR, thresholds=None, gap: float = HYSTERESIS_GAP,
+                 time_bins: int = TIME_BINS, n_samples: int = int(SAMPLE_RATE * DURATION)):
+        _lib.require_gpu()
+        if filterbank not in ("gammatone", "mel"):
+            raise ValueError(f"filterbank must be 'mel' or 'gammatone', got {filterbank!r}")
+        self.lib = _lib.load()
+        self.device = torch.device(device if device is not None else "cuda")
+        self.n_filters = int(n_filters)
+        self.filterbank = filterbank
+        self.redundancy = int(redundancy)
+        self.thresholds = list(SPIKE_THRESHOLDS if thresholds is None else thresholds)
+        self.gap = float(gap)
+        self.time_bins = int(time_bins)
+        self.n_samples = int(n_samples)
+        if filterbank == "gammatone":
+            hop_time = self.n_samples / (SAMPLE_RATE * self.time_bins)       # create_dataset.py:50
+            self.nwin, self.hop, self.ncols = gtgram_strides(SAMPLE_RATE, GT_WINDOW_TIME, hop_time,
+                                                             self.n_samples)
+            tab = gammatone_filter_table(SAMPLE_RATE, self.n_filters, GT_F_MIN)
+            self.coefs = torch.from_numpy(tab).to(self.device)
+            self.dtype = torch.float64
+        else:
+            from . import mel as _mel
+            self._mel = _mel.MelSpectrogram(self.n_filters, self.n_samples, self.time_bins, self.device)
+            self.ncols = self._mel.n_frames
+            self.dtype = torch.float32
+
+    @property
+    def n_channels(self) -> int:
+        return self.n_filters * self.redundancy
+
+    @property
+    def n_steps(self) -> int:
+        return self.time_bins * len(self.thresholds)
+
+    def _audio(self, audio) -> torch.Tensor:
+        if isinstance(audio, np.ndarray):
+            audio = torch.from_numpy(np.ascontiguousarray(audio, dtype=np.float32))
+        audio = audio.to(self.device, dtype=torch.float32).contiguous()
+        if audio.dim() == 1:
+            audio = audio[None]
+        if audio.shape[1] != self.n_samples:
+            raise ValueError(f"clips must have {self.n_samples} samples, got {audio.shape[1]}")
+        return audio
+
+    def spectrogram_db(self, audio, want_spec: bool = False):
+        """(B, n_samples) float32 -> dB spectrogram (B, F, ncols) in the filterbank's dtype
+        (gammatone: float64 20*log10(gtgram+1e-9), un-floored; mel: float32 power_to_db)."""
+        audio = self._audio(audio)
+        B = audio.shape[0]
+        if self.filterbank == "mel":
+            return self._mel.power_db(audio), None
+        db = torch.empty((B, self.n_filters, self.ncols), dtype=torch.float64, device=self.device)
+        spec = torch.empty_like(db) if want_spec else None
+        _lib.check(self.lib.lsm_gammatone_spec_f64(
+            _dev(audio), B, self.n_samples, _dev(self.coefs), self.n_filters, self.nwin, self.hop,
+            self.ncols, _dev(spec) if want_spec else None, _dev(db), _stream()),
+            "lsm_gammatone_spec_f64")
+        return db, spec
+
+    def spikes_from_db(self, db: torch.Tensor, want_norm: bool = False, want_raster: bool = True):
+        """dB spectrogram -> (uint8 raster (B, C, n_steps), normalised spectrogram or None)."""
+        B = db.shape[0]
+        f64 = db.dtype == torch.float64
+        np_dt = np.float64 if f64 else np.float32
+        on, off = threshold_tables(self.thresholds, self.gap, np_dt)
+        raster = (torch.empty((B, self.n_channels, self.n_steps), dtype=torch.uint8, device=self.device)
+                  if want_raster else None)
+        norm = (torch.empty((B, self.n_filters, self.time_bins), dtype=db.dtype, device=self.device)
+                if want_norm else None)
+        fn = self.lib.lsm_spec_to_spikes_f64 if f64 else self.lib.lsm_spec_to_spikes_f32
+        _lib.check(fn(_dev(db), B, self.n_filters, db.shape[2], self.time_bins,
+                      1 if self.filterbank == "gammatone" else 0, _host(on), _host(off), len(on),
+                      self.redundancy, _dev(raster) if want_raster else None,
+                      _dev(norm) if want_norm else None, _stream()), "lsm_spec_to_spikes")
+        return raster, norm
+
+    def encode(self, audio) -> torch.Tensor:
+        """audio (B, n_samples) -> uint8 spike raster (B, C, n_steps) on the device."""
+        db, _ = self.spectrogram_db(audio)
+        raster, _ = self.spikes_from_db(db)
+        return raster
+
+
+_FRONT_ENDS: dict = {}
+
+
+def _front_end(n_filters: int, filterbank: str, n_samples: int) -> SpikeFrontEnd:
+    key = (int(n_filters), filterbank, int(n_samples))
+    if key not in _FRONT_ENDS:
+        _FRONT_ENDS[key] = SpikeFrontEnd(n_filters, filterbank, n_samples=n_samples)
+    return _FRONT_ENDS[key]
+
+
+def audio_to_spectrogram(audio: np.ndarray, n_filters: int, filterbank: str) -> np.ndarray:
+    """create_dataset.py:39-78 for one clip: (n_samples,) -> (n_filters, TIME_BINS) in [0, 1]
+    (float64 for gammatone, float32 for mel and for the flat-input zeros, as in the reference)."""
+    fe = _front_end(n_filters, filterbank, len(audio))
+    db, _ = fe.spectrogram_db(np.asarray(audio, dtype=np.float32))
+    _, norm = fe.spikes_from_db(db, want_norm=True, want_raster=False)
+    hi, lo = db.max(), db.min()
+    if filterbank == "gammatone":
+        lo = torch.maximum(lo, hi - 80.0)                  # create_dataset.py:60
+    if float(hi - lo) < 1e-8:                              # create_dataset.py:64-65
+        return np.zeros((n_filters, TIME_BINS), dtype=np.float32)
+    return norm[0].cpu().numpy()
+
+
+def convert_spectrogram_to_spikes_hysteresis(spectrogram, thresholds, hysteresis_gap=0.05):
+    """create_dataset.py:81-98: (F, n_time) float -> (F, n_time*len(thresholds)) uint8."""
+    _lib.require_gpu()
+    lib = _lib.load()
+    spec = np.ascontiguousarray(spectrogram)
+    if spec.dtype not in (np.float32, np.float64):
+        spec = spec.astype(np.float64)
+    F, n_time = spec.shape
+    on, off = threshold_tables(thresholds, hysteresis_gap, spec.dtype.type)
+    dspec = torch.from_numpy(spec).cuda()
+    out = torch.empty((F, n_time * len(on)), dtype=torch.uint8, device="cuda")
+    fn = lib.lsm_encode_hysteresis_f64 if spec.dtype == np.float64 else lib.lsm_encode_hysteresis_f32
+    _lib.check(fn(_dev(dspec), F, n_time, _host(on), _host(off), len(on), _dev(out), _stream()),
+               "lsm_encode_hysteresis")
+    return out.cpu().numpy()
+
+
+def create_pure_redundancy(spike_train: np.ndarray, redundancy_factor: int) -> np.ndarray:
+    """create_dataset.py:101-104 (host copy; the batched path repeats rows inside the kernel)."""
+    return np.repeat(spike_train, redundancy_factor, axis=0)

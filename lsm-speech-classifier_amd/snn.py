@@ -1,0 +1,133 @@
+"""Host mirror of the reference's reservoir object protocol over the HIP reservoir kernel.
+
+``SNN`` / ``SimulationParams`` stand in for ``snnpy.snn.SNN`` / ``SimulationParams`` as the
+reference uses them (/root/reference/extract_lsm_features.py:2,79-83,100,109-116,164-188):
+``SNN(simulation_params=P)``, ``.reset()``, ``.set_input_spike_times(u8 (C, T))``, ``.simulate()``,
+``.extract_features_from_spikes() -> dict``, attributes ``.num_neurons`` and ``.spike_matrix``
+(T, N).  ``run_batch`` is the batched path ``extract_all_features`` uses.  All arithmetic runs
+in liblsm_hip.so; there is no CPU fallback.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib
+from .reservoir import Reservoir, SimulationParams, build_reservoir
+
+# FEATURE_SETS['all'] order (extract_lsm_features.py:20-22) = key ids of the C ABI
+FEATURE_KEYS = ['spike_counts', 'spike_variances', 'mean_spike_times', 'first_spike_times',
+                'last_spike_times', 'mean_isi', 'isi_variances', 'burst_counts']
+
+__all__ = ["SNN", "SimulationParams", "FEATURE_KEYS"]
+
+
+def _dev(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else None
+
+
+def _host(a):
+    return C.c_void_p(a.ctypes.data)
+
+
+class SNN:
+    def __init__(self, simulation_params: SimulationParams, n_channels: int | None = None,
+                 device=None, reservoir: Reservoir | None = None):
+        _lib.require_gpu()
+        self.lib = _lib.load()
+        self.params = simulation_params
+        self.device = torch.device(device if device is not None else "cuda")
+        if reservoir is None:
+            if n_channels is None:
+                ist = simulation_params.input_spike_times
+                if ist is None:
+                    raise ValueError("SNN needs n_channels or simulation_params.input_spike_times")
+                n_channels = int(np.asarray(ist).shape[0])
+            reservoir = build_reservoir(simulation_params, n_channels)
+        self.reservoir = reservoir
+        self.num_neurons = reservoir.num_neurons
+        self.n_channels = reservoir.n_channels
+        self.num_output_neurons = len(reservoir.out_idx)
+        self._handle = C.c_void_p()
+        r = reservoir
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.lsm_reservoir_create(
+                C.byref(self._handle), r.num_neurons, r.n_channels, _host(r.csc_ptr),
+                _host(r.csc_post), _host(r.csc_w), _host(r.leak),
+                _host(np.ascontiguousarray(r.in_tgt, dtype=np.int32)), int(r.in_fanout),
+                float(r.w_in), _host(r.out_idx), len(r.out_idx), float(r.theta),
+                int(r.refractory_period), int(r.burst_isi_max)), "lsm_reservoir_create")
+        self._input = None
+        self.spike_matrix = None
+        self._features = None
+
+    def __del__(self):
+        h = getattr(self, "_handle", None)
+        if h is not None and h.value:
+            self.lib.lsm_reservoir_destroy(h)
+            self._handle = C.c_void_p()
+
+    # ---- batched path -------------------------------------------------------------------
+    def run_batch(self, spikes, feature_keys=None, want_spike_matrix=False, want_v_trace=False,
+                  waves_per_clip: int = 0):
+        """spikes: uint8 (B, C, T) torch tensor on this device (or NumPy, copied).  Returns
+        (features float32 (B, n_keys*N_out) device tensor, spike_matrix or None, v_trace or None);
+        NaN entries are already 0 and keys are concatenated in the given order
+        (extract_lsm_features.py:85-87)."""
+        if isinstance(spikes, np.ndarray):
+            spikes = torch.from_numpy(np.ascontiguousarray(spikes, dtype=np.uint8))
+        spikes = spikes.to(self.device, dtype=torch.uint8).contiguous()
+        if spikes.dim() != 3 or spikes.shape[1] != self.n_channels:
+            raise ValueError(f"spikes must be (B, {self.n_channels}, T), got {tuple(spikes.shape)}")
+        B, _, T = spikes.shape
+        keys = FEATURE_KEYS if feature_keys is None else [k for k in feature_keys if k in FEATURE_KEYS]
+        key_ids = np.array([FEATURE_KEYS.index(k) for k in keys], dtype=np.int32)
+        feats = torch.empty((B, len(keys) * self.num_output_neurons), dtype=torch.float32,
+                            device=self.device)
+        sm = (torch.empty((B, T, self.num_neurons), dtype=torch.uint8, device=self.device)
+              if want_spike_matrix else None)
+        vt = (torch.empty((B, T, self.num_neurons), dtype=torch.float32, device=self.device)
+              if want_v_trace else None)
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.lsm_reservoir_run(
+                self._handle, _dev(spikes), B, T, _host(key_ids), len(keys), _dev(feats), _dev(sm),
+                _dev(vt), int(waves_per_clip), torch.cuda.current_stream().cuda_stream),
+                "lsm_reservoir_run")
+        return feats, sm, vt
+
+    def layout(self, n_clips: int, n_steps: int, waves_per_clip: int = 0):
+        wpc, sl, lds = C.c_int(), C.c_int(), C.c_int()
+        _lib.check(self.lib.lsm_reservoir_layout(self._handle, n_clips, n_steps, waves_per_clip,
+                                                 C.byref(wpc), C.byref(sl), C.byref(lds)))
+        return {"waves_per_clip": wpc.value, "slots_per_lane": sl.value, "lds_bytes": lds.value}
+
+    # ---- the reference's single-clip protocol -------------------------------------------
+    def reset(self):
+        self._input = None
+        self.spike_matrix = None
+        self._features = None
+
+    def set_input_spike_times(self, sample):
+        self._input = np.ascontiguousarray(sample, dtype=np.uint8)
+
+    def simulate(self):
+        if self._input is None:
+            raise RuntimeError("simulate() before set_input_spike_times()")
+        feats, sm, _ = self.run_batch(self._input[None], FEATURE_KEYS, want_spike_matrix=True)
+        self.spike_matrix = sm[0].cpu().numpy()
+        self._features = feats[0].cpu().numpy().reshape(len(FEATURE_KEYS), self.num_output_neurons)
+
+    def extract_features_from_spikes(self) -> dict:
+        """dict[str -> (N_out,) float32]; entries that are undefined for a silent neuron are NaN
+        here (the batched path returns them as 0, which is what the caller's nan_to_num makes)."""
+        if self._features is None:
+            raise RuntimeError("extract_features_from_spikes() before simulate()")
+        f = {k: self._features[i].copy() for i, k in enumerate(FEATURE_KEYS)}
+        n = f['spike_counts']
+        for k in ('mean_spike_times', 'first_spike_times', 'last_spike_times'):
+            f[k][n < 1] = np.nan
+        for k in ('mean_isi', 'isi_variances'):
+            f[k][n < 2] = np.nan
+        return f

@@ -228,7 +228,7 @@ ORC_API int orc_lif_run(int N, int C, int T,
             for (int e = csr_ptr[i]; e < csr_ptr[i + 1]; ++e)
                 cur += csr_w[e] * (float)s_prev[csr_pre[e]];
             for (int e = in_ptr[i]; e < in_ptr[i + 1]; ++e)
-                cur += w_in * (float)raster[(size_t)in_chan[e] * T + t];
+                cur += w_in * (float)(raster[(size_t)in_chan[e] * T + t] != 0);   /* any non-zero byte is a spike */
             int fire = 0;
             if (ref[i] > 0) {
                 ref[i] -= 1;

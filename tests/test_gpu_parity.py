@@ -1,0 +1,245 @@
+"""HIP path vs the CPU oracle on identical seeded inputs (run on the MI355X box: -m gpu).
+
+Bars: bit-exact for every integer/byte result (rasters, spike matrices, counts) and — because the
+kernels repeat the oracle's float operation order with contraction off — also for the float
+results (gammatone spectrogram, membrane traces, features).  log10 is the one exception: dB
+values are compared at 1e-12 absolute (values are O(100)), and the rasters derived from them
+must still be identical.
+"""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+THR = [0.70, 0.80, 0.90, 0.95]
+GAP = 0.1
+
+
+@pytest.fixture(scope="module")
+def torch_cuda():
+    import torch
+    assert torch.cuda.is_available(), "GPU tests need a HIP device"
+    from lsm_speech_classifier_amd import _lib
+    _lib.require_gpu()
+    return torch
+
+
+def _mixed_audio(n, seed):
+    from lsm_speech_classifier_amd import synth
+    a = synth.class_chirps(list(range(n)), seed=seed)
+    a[n // 2:] = synth.white_noise(n - n // 2, seed=seed + 1)
+    return a
+
+
+# ----------------------------------------------------------------------------- front end ----
+@pytest.mark.parametrize("n_filters", [2, 40, 128])
+def test_gammatone_frontend_matches_oracle(torch_cuda, oracle_c, n_filters):
+    from lsm_speech_classifier_amd import frontend
+    from oracle import ref_numpy as O
+    audio = _mixed_audio(4, seed=11 + n_filters)
+    fe = frontend.SpikeFrontEnd(n_filters, "gammatone")
+    assert (fe.nwin, fe.hop, fe.ncols) == (400, 160, 98)
+    coefs = O.gammatone_coefs(16000, n_filters, 50)
+    np.testing.assert_array_equal(frontend.gammatone_filter_table(16000, n_filters, 50), coefs)
+    db, spec = fe.spectrogram_db(audio, want_spec=True)
+    raster, norm = fe.spikes_from_db(db, want_norm=True)
+    spec, db, norm, raster = (t.cpu().numpy() for t in (spec, db, norm, raster))
+    for b in range(len(audio)):
+        s_ref = oracle_c.gammatone_spec(audio[b], coefs, 400, 160, 98)
+        np.testing.assert_array_equal(spec[b], s_ref)                       # bit-exact float64
+        np.testing.assert_allclose(db[b], 20 * np.log10(s_ref + 1e-9), rtol=0, atol=1e-12)
+        n_ref = oracle_c.normalise_resize(oracle_c.gammatone_db(s_ref))
+        np.testing.assert_allclose(norm[b], n_ref, rtol=0, atol=1e-13)
+        r_ref = oracle_c.encode_hysteresis(n_ref, THR, GAP)
+        np.testing.assert_array_equal(raster[b], r_ref)
+        assert raster[b].dtype == np.uint8 and raster[b].shape == (n_filters, 400)
+
+
+def test_frontend_against_numpy_scipy_restatement(torch_cuda):
+    """Same path against the literal NumPy/SciPy restatement (scipy.signal.lfilter inside)."""
+    from lsm_speech_classifier_amd import frontend
+    from oracle import ref_numpy as O
+    audio = _mixed_audio(2, seed=5)
+    fe = frontend.SpikeFrontEnd(64, "gammatone")
+    db, spec = fe.spectrogram_db(audio, want_spec=True)
+    raster, _ = fe.spikes_from_db(db)
+    for b in range(2):
+        g = O.gtgram(audio[b], 16000, 0.025, 0.01, 64, 50)
+        np.testing.assert_array_equal(spec[b].cpu().numpy(), g)
+        r = O.encode_hysteresis(O.normalise_resize(O.gammatone_db(g)), THR, GAP)
+        np.testing.assert_array_equal(raster[b].cpu().numpy(), r)
+
+
+def test_encoder_matches_reference_golden(torch_cuda, golden_dir):
+    from lsm_speech_classifier_amd import frontend
+    g = np.load(os.path.join(golden_dir, "encoder.npz"))
+    names = sorted(k[:-3] for k in g.files if k.endswith("_in") and not k.startswith("gap005"))
+    for n in names:
+        out = frontend.convert_spectrogram_to_spikes_hysteresis(g[n + "_in"], list(g["thresholds"]),
+                                                                float(g["gap"]))
+        np.testing.assert_array_equal(out, g[n + "_out"], err_msg=n)
+    out = frontend.convert_spectrogram_to_spikes_hysteresis(g["gap005_float64_in"], [0.5, 0.9, 0.3])
+    np.testing.assert_array_equal(out, g["gap005_float64_out"])
+
+
+def test_postfilter_matches_reference_golden(torch_cuda, golden_dir):
+    """create_dataset.py:59-78 fixtures: normalise + zoom + crop on the GPU."""
+    import torch
+    from lsm_speech_classifier_amd import frontend
+    g = np.load(os.path.join(golden_dir, "postfilter.npz"))
+    for n in ("gt_a", "gt_b", "gt_c", "gt_flat"):
+        spec = g[n + "_in"]
+        fe = frontend.SpikeFrontEnd(spec.shape[0], "gammatone")
+        db = torch.from_numpy(20 * np.log10(spec + 1e-9))[None].cuda()
+        raster, norm = fe.spikes_from_db(db, want_norm=True)
+        ref = g[n + "_out"].astype(np.float64)
+        np.testing.assert_allclose(norm[0].cpu().numpy(), ref, rtol=0, atol=1e-13, err_msg=n)
+        from oracle import ref_numpy as O
+        np.testing.assert_array_equal(raster[0].cpu().numpy(), O.encode_hysteresis(ref, THR, GAP))
+    for n in ("mel_a", "mel_b"):
+        db = g[n + "_in"]
+        fe = frontend.SpikeFrontEnd.__new__(frontend.SpikeFrontEnd)       # shape-only instance
+        fe.__dict__.update(lib=frontend._lib.load(), device=torch.device("cuda"),
+                           n_filters=db.shape[0], filterbank="mel", redundancy=1, thresholds=THR,
+                           gap=GAP, time_bins=100)
+        raster, norm = fe.spikes_from_db(torch.from_numpy(db)[None].cuda(), want_norm=True)
+        np.testing.assert_array_equal(norm[0].cpu().numpy(), g[n + "_out"], err_msg=n)   # float32 bit-exact
+
+
+def test_redundancy_rows(torch_cuda):
+    from lsm_speech_classifier_amd import frontend
+    audio = _mixed_audio(2, seed=3)
+    r1 = frontend.SpikeFrontEnd(16, "gammatone", redundancy=1).encode(audio).cpu().numpy()
+    r3 = frontend.SpikeFrontEnd(16, "gammatone", redundancy=3).encode(audio).cpu().numpy()
+    np.testing.assert_array_equal(r3, np.repeat(r1, 3, axis=1))
+
+
+def test_flat_and_silent_audio(torch_cuda):
+    from lsm_speech_classifier_amd import frontend
+    out = frontend.audio_to_spectrogram(np.zeros(16000, dtype=np.float32), 8, "gammatone")
+    assert out.shape == (8, 100) and out.dtype == np.float32 and not out.any()
+    fe = frontend.SpikeFrontEnd(8, "gammatone")
+    assert int(fe.encode(np.zeros((1, 16000), dtype=np.float32)).sum()) == 0
+
+
+# ----------------------------------------------------------------------------- reservoir ----
+def _reservoir(n, k, n_out, c, rasters, **kw):
+    from lsm_speech_classifier_amd import reservoir as R
+    from oracle import ref_numpy as O
+    wc = O.w_critico(k, 2.0, kw.get("refractory_period", 2), rasters)
+    p = R.SimulationParams(num_neurons=n, num_output_neurons=n_out, small_world_graph_k=k,
+                           mean_weight=wc * kw.pop("multiplier", 0.6), **kw)
+    return R.build_reservoir(p, c)
+
+
+def _check_against_oracle(net, rasters, oracle_c, wpc, keys=None):
+    feats, sm, vt = net.run_batch(rasters, keys, want_spike_matrix=True, want_v_trace=True,
+                                  waves_per_clip=wpc)
+    feats, sm, vt = feats.cpu().numpy(), sm.cpu().numpy(), vt.cpu().numpy()
+    total = 0
+    for b in range(len(rasters)):
+        f_ref, sm_ref, vt_ref = oracle_c.lif_run(net.reservoir, rasters[b], keys, want_trace=True)
+        np.testing.assert_array_equal(sm[b], sm_ref, err_msg=f"spike matrix clip {b} wpc {wpc}")
+        np.testing.assert_array_equal(vt[b], vt_ref, err_msg=f"membrane trace clip {b} wpc {wpc}")
+        np.testing.assert_array_equal(feats[b], f_ref, err_msg=f"features clip {b} wpc {wpc}")
+        total += int(sm_ref.sum())
+    return total
+
+
+@pytest.mark.parametrize("n,k,n_out,c,wpcs", [
+    (200, 40, 80, 32, (1, 2, 4)),
+    (500, 100, 200, 40, (1, 2, 4, 8)),
+    (1000, 200, 400, 128, (1, 2, 4, 8, 16)),
+])
+def test_reservoir_matches_oracle_all_layouts(torch_cuda, oracle_c, n, k, n_out, c, wpcs):
+    from lsm_speech_classifier_amd import snn, synth
+    rasters = synth.bernoulli_raster(3, c, 400, 0.2, seed=n)
+    rasters[2] = synth.bernoulli_raster(1, c, 400, 0.05, seed=n + 1)[0]
+    res = _reservoir(n, k, n_out, c, rasters)
+    net = snn.SNN(None, reservoir=res)
+    for wpc in wpcs:
+        total = _check_against_oracle(net, rasters, oracle_c, wpc)
+        assert total > 0, "test input must make the reservoir spike"
+
+
+def test_reservoir_edge_cases(torch_cuda, oracle_c):
+    from lsm_speech_classifier_amd import snn, synth
+    c = 24
+    base = synth.bernoulli_raster(2, c, 96, 0.3, seed=9)
+    cases = {
+        "silent": np.zeros((1, c, 96), dtype=np.uint8),
+        "saturated": np.ones((1, c, 96), dtype=np.uint8),
+        "odd_T": synth.bernoulli_raster(2, c, 37, 0.4, seed=10),          # T % 4 != 0 path
+        "byte_values": (base * 7).astype(np.uint8),                        # any non-zero byte = spike
+        "single_step": synth.bernoulli_raster(1, c, 1, 0.9, seed=12),
+    }
+    for mult, refr, div in ((0.6, 2, None), (3.0, 0, None), (1.5, 5, 4.0)):
+        res = _reservoir(130, 20, 130, c, base, multiplier=mult, refractory_period=refr,
+                         leak_variance_divisor=div)
+        net = snn.SNN(None, reservoir=res)
+        for name, r in cases.items():
+            for wpc in (1, 2):
+                _check_against_oracle(net, r, oracle_c, wpc)
+    silent_feats, sm, _ = net.run_batch(cases["silent"], want_spike_matrix=True)
+    assert int(sm.sum()) == 0 and not silent_feats.cpu().numpy().any()
+    # empty batch is a no-op
+    feats, _, _ = net.run_batch(np.zeros((0, c, 96), dtype=np.uint8))
+    assert feats.shape[0] == 0
+
+
+def test_feature_sets_and_snn_protocol(torch_cuda, oracle_c, golden_dir):
+    """Key subsets/order (FEATURE_SETS, extract_lsm_features.py:19-28) and the single-clip
+    reset/set_input/simulate/extract protocol (extract_lsm_features.py:79-87)."""
+    from lsm_speech_classifier_amd import snn, synth
+    from oracle import ref_numpy as O
+    g = np.load(os.path.join(golden_dir, "constants.npz"))
+    c = 32
+    rasters = synth.bernoulli_raster(2, c, 400, 0.25, seed=21)
+    res = _reservoir(256, 50, 100, c, rasters)
+    net = snn.SNN(None, reservoir=res)
+    for name in g["feature_set_names"]:
+        keys = [str(k) for k in g[f"feature_set_{name}"]]
+        _check_against_oracle(net, rasters, oracle_c, 0, keys)
+    net.reset()
+    net.set_input_spike_times(rasters[0])
+    net.simulate()
+    d = net.extract_features_from_spikes()
+    sm_ref, _ = O.lif_run(res, rasters[0])
+    np.testing.assert_array_equal(net.spike_matrix, sm_ref)
+    ref = O.spike_features(sm_ref, res.out_idx, res.burst_isi_max)
+    for kname in O.FEATURE_KEYS:
+        np.testing.assert_array_equal(np.isnan(d[kname]), np.isnan(ref[kname]), err_msg=kname)
+        np.testing.assert_allclose(np.nan_to_num(d[kname]), np.nan_to_num(ref[kname]), rtol=1e-6,
+                                   atol=0, err_msg=kname)
+    assert net.num_neurons == 256
+
+
+def test_full_size_properties(torch_cuda, oracle_c):
+    """BASELINE configs[1] shape (F=128, N=1000, N_out=400, B=256): size-independent properties
+    plus a spot check of a few clips against the oracle."""
+    import torch
+    from lsm_speech_classifier_amd import snn, synth
+    B, c, T = 256, 128, 400
+    rasters = synth.bernoulli_raster(B, c, T, 0.2, seed=1234)
+    rasters[7] = 0                                       # a silent clip
+    rasters[100] = rasters[3]                            # duplicates must give identical rows
+    res = _reservoir(1000, 200, 400, c, rasters)
+    net = snn.SNN(None, reservoir=res)
+    dev = torch.from_numpy(rasters).cuda()
+    feats, _, _ = net.run_batch(dev, waves_per_clip=0)
+    f = feats.cpu().numpy()
+    counts = f[:, :400]
+    assert counts.max() <= -(-T // (res.refractory_period + 1))          # <= ceil(T/(R+1))
+    assert np.all(counts == np.round(counts)) and counts.min() >= 0
+    assert not f[7].any()                                                # zero input => zero spikes
+    np.testing.assert_array_equal(f[100], f[3])
+    perm = np.random.RandomState(0).permutation(B)                       # batch order independence
+    f2, _, _ = net.run_batch(dev[torch.from_numpy(perm).cuda()], waves_per_clip=0)
+    np.testing.assert_array_equal(f2.cpu().numpy(), f[perm])
+    for wpc in (1, 4, 16):                                               # layouts agree
+        fw, _, _ = net.run_batch(dev, waves_per_clip=wpc)
+        np.testing.assert_array_equal(fw.cpu().numpy(), f)
+    ref = oracle_c.lif_run_batch(res, rasters[:6], n_threads=6)
+    np.testing.assert_array_equal(f[:6], ref)
