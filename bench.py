@@ -1,0 +1,243 @@
+#!/usr/bin/env python3
+"""Hot-path benchmark (driver contract: python bench.py --gpus N --steps K --warmup W).
+
+One STEP = one pass of the whole hot path over one batch of synthetic clips per GPU, inputs
+already resident in HBM: audio (B, 16000) f32 -> gammatone filterbank -> dB/normalise/resize ->
+hysteresis encoder -> uint8 raster (B, C, 400) -> LIF reservoir (400 steps) -> features
+(B, 5*N_out) f32 [-> RCCL all-gather of the feature rows when N > 1].  Default workload is
+BASELINE.json configs[1]: 128 gammatone filters, 1000-neuron reservoir, batch 256 per GPU,
+`original` feature set, multiplier 0.6.  Clips shard across ranks (weak scaling, no data-path
+collective except the final feature gather the reference's single-process run implies).
+
+Prints ONE JSON line on rank 0 with the contract keys plus `roofline` (LIF kernel, algorithmic
+bytes of SURVEY.md §8(d) / measured HIP-event time) and, at N=1, `cpu_baseline` (the C oracle
+timed on the host cores on a bounded sample of the same workload).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import numpy as np
+import torch
+
+CONFIGS = {
+    # name: (n_filters, filterbank, N, k, N_out, batch per GPU, audio kind)
+    "cfg2": dict(n_filters=128, filterbank="gammatone", N=1000, k=200, n_out=400, batch=256,
+                 audio="speech_like", desc="12-class-like synthetic speech, 128 gammatone filters, "
+                 "1000-neuron reservoir, batch=256 per GPU"),
+    "cfg4": dict(n_filters=128, filterbank="gammatone", N=4000, k=800, n_out=1600, batch=1024,
+                 audio="speech_like", desc="128 filters, 4000-neuron reservoir, batch=1024 per GPU"),
+    "cfg5": dict(n_filters=256, filterbank="gammatone", N=8000, k=1600, n_out=3200, batch=4096,
+                 audio="white_noise", desc="white-noise clips, 256 filters, 8000-neuron reservoir, "
+                 "batch=4096 per GPU (HBM roofline stress)"),
+}
+FEATURE_SET = ['spike_counts', 'spike_variances', 'mean_spike_times', 'mean_isi', 'isi_variances']
+MULTIPLIER = 0.6
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8 TB/s spec
+
+
+def w_critico(k, theta, refractory, rasters_dev):
+    """extract_lsm_features.py:33-60 on the first <=500 clips (device reduction, host scalar)."""
+    sub = rasters_dev[:500]
+    if sub.numel() == 0 or k == 0:
+        return 0.007
+    avg_i = float(sub.sum(dtype=torch.int64)) / sub.numel()
+    return (theta - 2 * avg_i * refractory) / (k / 2)
+
+
+def make_audio(kind, n, seed):
+    from lsm_speech_classifier_amd import synth
+    if kind == "white_noise":
+        return synth.white_noise(n, seed=seed)
+    return synth.class_chirps(np.arange(n) % 12, seed=seed)
+
+
+def cpu_baseline(cfg, audio, res, seconds_budget=20.0):
+    """C oracle (oracle/, kind 'port') on a bounded sample: one clip at a time on one core, like
+    the reference's serial loops (create_dataset.py:143, extract_lsm_features.py:78); then the
+    same sample with one clip per core."""
+    from lsm_speech_classifier_amd import frontend
+    from oracle import cport, ref_numpy
+    cport.build()
+    coefs = ref_numpy.gammatone_coefs(16000, cfg["n_filters"], 50)
+
+    def front(a):
+        return cport.encode_hysteresis(cport.normalise_resize(cport.gammatone_db(
+            cport.gammatone_spec(a, coefs, 400, 160, 98))), frontend.SPIKE_THRESHOLDS,
+            frontend.HYSTERESIS_GAP)
+
+    def one(a):
+        return cport.lif_run(res, front(a), FEATURE_SET, want_spikes=False)[0]
+
+    one(audio[0])                                   # warm-up
+    t0 = time.perf_counter()
+    one(audio[1 % len(audio)])
+    per_clip = time.perf_counter() - t0
+    n = int(max(2, min(len(audio), seconds_budget / 2 / max(per_clip, 1e-4))))
+    t0 = time.perf_counter()
+    for a in audio[:n]:
+        one(a)
+    t_serial = time.perf_counter() - t0
+    cores = os.cpu_count() or 1
+    rasters = np.stack([front(a) for a in audio[:n]])
+    t0 = time.perf_counter()
+    cport.lif_run_batch(res, rasters, FEATURE_SET, n_threads=cores)
+    t_lif_all = time.perf_counter() - t0
+    t_front = 0.0
+    t1 = time.perf_counter()
+    front(audio[0])
+    t_front = time.perf_counter() - t1
+    return {
+        "value": round(n / t_serial, 3), "unit": "clips/s", "cores": 1, "kind": "port",
+        "sample": f"{n} clips of the same workload, C oracle (gather-form LIF + gammatone), one clip "
+                  f"at a time on one core; front end {t_front * 1e3:.1f} ms/clip",
+        "all_cores": {"value": round(n / (t_lif_all + n * t_front / cores), 3), "cores": cores,
+                      "note": "reservoir with one clip per OpenMP thread; front-end time divided by cores"},
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--config", default="cfg2", choices=sorted(CONFIGS))
+    ap.add_argument("--batch", type=int, default=0, help="clips per GPU (0 = the config's)")
+    ap.add_argument("--waves-per-clip", type=int, default=0)
+    ap.add_argument("--stage", default="full", choices=["full", "reservoir", "frontend"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    else:
+        torch.cuda.set_device(0)
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    dev = torch.device("cuda", local_rank if world > 1 else 0)
+
+    from lsm_speech_classifier_amd import frontend, reservoir, snn
+    cfg = CONFIGS[args.config]
+    B = args.batch or cfg["batch"]
+    fe = frontend.SpikeFrontEnd(cfg["n_filters"], cfg["filterbank"], device=dev)
+    audio_np = make_audio(cfg["audio"], B, seed=1234 + 1000 * rank)
+    audio = torch.from_numpy(audio_np).to(dev)
+
+    # one-off setup exactly like extract_lsm_features.main: rasters -> w_critico -> reservoir
+    rasters0 = fe.encode(audio)
+    wc = w_critico(cfg["k"], 2.0, 2, rasters0)
+    if world > 1:                                  # every rank must build the SAME reservoir
+        t = torch.tensor([wc], dtype=torch.float64, device=dev)
+        dist.broadcast(t, 0)
+        wc = float(t.item())
+    params = reservoir.SimulationParams(num_neurons=cfg["N"], num_output_neurons=cfg["n_out"],
+                                        small_world_graph_k=cfg["k"], mean_weight=wc * MULTIPLIER)
+    res = reservoir.build_reservoir(params, fe.n_channels)
+    net = snn.SNN(params, reservoir=res, device=dev)
+    n_feat = len(FEATURE_SET) * cfg["n_out"]
+    gathered = torch.empty((world * B, n_feat), dtype=torch.float32, device=dev) if world > 1 else None
+    lay = net.layout(B, fe.n_steps, args.waves_per_clip)
+
+    ev_pairs = []
+
+    def step(timed):
+        if args.stage == "reservoir":
+            rasters = rasters0
+        else:
+            rasters = fe.encode(audio)
+        if args.stage == "frontend":
+            return rasters
+        if timed:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+        feats, _, _ = net.run_batch(rasters, FEATURE_SET, waves_per_clip=args.waves_per_clip)
+        if timed:
+            e1.record()
+            ev_pairs.append((e0, e1))
+        if world > 1:
+            dist.all_gather_into_tensor(gathered, feats)
+            return gathered
+        return feats
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        out = step(False)
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step(True)
+    fence()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    spikes_per_clip = None
+    if args.stage != "frontend":
+        fl = out[:B].float()
+        spikes_per_clip = float(fl[:, :cfg["n_out"]].sum(dim=1).mean())
+
+    if rank == 0:
+        ms_step = elapsed / args.steps * 1e3
+        value = world * B * args.steps / elapsed
+        line = {
+            "metric": "clips/sec (1 s@16 kHz, 128-filter, 1000-neuron LSM)" if args.config == "cfg2"
+                      else f"clips/sec ({args.config})",
+            "value": round(value, 2), "unit": "clips/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(ms_step, 4), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32 (reservoir) / f64 (gammatone)",
+            "data": "synthetic",
+            "config": {"workload": f"{args.config}: {cfg['desc']}", "stage": args.stage,
+                       "clips_per_gpu": B, "n_filters": cfg["n_filters"], "num_neurons": cfg["N"],
+                       "small_world_k": cfg["k"], "num_output_neurons": cfg["n_out"],
+                       "time_steps": fe.n_steps, "feature_set": "original",
+                       "waves_per_clip": lay["waves_per_clip"], "lds_bytes_per_clip": lay["lds_bytes"],
+                       "mean_output_spikes_per_clip": spikes_per_clip,
+                       "sharding": f"clips x{world}, feature all-gather" if world > 1 else "single GPU"},
+        }
+        if ev_pairs:
+            lif_ms = sum(a.elapsed_time(b) for a, b in ev_pairs) / len(ev_pairs)
+            w_bytes = res.csr_bytes()
+            per_clip = fe.n_channels * fe.n_steps + n_feat * 4 + fe.n_steps * w_bytes / B
+            compulsory = fe.n_channels * fe.n_steps + n_feat * 4 + w_bytes / B
+            achieved = per_clip * B / (lif_ms * 1e-3) / 1e9
+            traffic = None
+            tfile = os.path.join(ROOT, "profiles", "lif_traffic.json")
+            if os.path.exists(tfile):
+                traffic = json.load(open(tfile)).get(f"{args.config}_B{B}")
+            line["roofline"] = {
+                "bound": "hbm", "kernel": "lif_kernel", "achieved": round(achieved, 2),
+                "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
+                "traffic": traffic, "kernel_ms": round(lif_ms, 4),
+                "bytes_per_clip": round(per_clip, 1),
+                "variant": "streamed (C*T + 4*F_feat + T*|W|/B, SURVEY.md 8d); |W| = 8 B x nnz",
+                "compulsory_bytes_per_clip": round(compulsory, 1),
+                "compulsory_gbs": round(compulsory * B / (lif_ms * 1e-3) / 1e9, 3),
+                "kernel_clips_per_s": round(B / (lif_ms * 1e-3), 1),
+            }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(cfg, audio_np, res)
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -45,10 +45,13 @@ int lsm_device_count(void);
  *           rows [A0, A11, A12, A13, A14, A2, B0, B1, B2, gain], low -> high centre frequency
  *   spec_out (n_clips, n_filters, ncols) float64 or NULL: sqrt(mean of squared filter output)
  *   db_out   (n_clips, n_filters, ncols) float64 or NULL: 20*log10(spec + 1e-9)
- * nwin/hop are in samples (400/160 for the reference call), nwin <= 4*hop. */
+ * nwin/hop are in samples (400/160 for the reference call), nwin <= 4*hop.
+ * coef_flags (properties of the coefficient table the HOST has verified; 0 is always valid):
+ *   bit 0  every A2 is exactly 0  -> the x*A2 products (signed zeros) are not evaluated
+ *   bit 1  no gain has an all-ones significand -> y/gain through the exact Markstein FMA sequence */
 int lsm_gammatone_spec_f64(const float *audio, int n_clips, int n_samples, const double *coefs_dev,
                            int n_filters, int nwin, int hop, int ncols, double *spec_out,
-                           double *db_out, void *stream);
+                           double *db_out, int coef_flags, void *stream);
 
 /* Replaces create_dataset.py:60 (apply_floor: max-80 dB floor), :62-78 (min-max normalise with
  * eps 1e-8, flat input -> zeros, scipy zoom(order=1) to time_bins columns, crop), :81-98
@@ -107,6 +110,10 @@ int lsm_reservoir_run(const lsm_reservoir *h, const uint8_t *spikes_u8, int n_cl
 /* Layout that lsm_reservoir_run would use: waves per clip, 64-neuron slots per lane, LDS bytes. */
 int lsm_reservoir_layout(const lsm_reservoir *h, int n_clips, int n_steps, int waves_per_clip,
                          int *wpc_out, int *slots_out, int *lds_bytes_out);
+
+/* Diagnostic builds (-DLSM_STAMP=1) only: per-phase s_memtime sums of the reservoir kernel
+ * (out8: 8 counters, HOST memory); all zeros in the shipped build. */
+int lsm_debug_lif_stamps(unsigned long long *out8, int reset);
 
 #ifdef __cplusplus
 }

@@ -18,7 +18,7 @@ _SIGS = {
     "lsm_last_error": (C.c_char_p, []),
     "lsm_device_count": (c_int, []),
     "lsm_gammatone_spec_f64": (c_int, [c_void, c_int, c_int, c_void, c_int, c_int, c_int, c_int,
-                                       c_void, c_void, c_void]),
+                                       c_void, c_void, c_int, c_void]),
     "lsm_spec_to_spikes_f64": (c_int, [c_void, c_int, c_int, c_int, c_int, c_int, c_void, c_void,
                                        c_int, c_int, c_void, c_void, c_void]),
     "lsm_spec_to_spikes_f32": (c_int, [c_void, c_int, c_int, c_int, c_int, c_int, c_void, c_void,
@@ -32,6 +32,7 @@ _SIGS = {
                                   c_void, c_int, c_void]),
     "lsm_reservoir_layout": (c_int, [c_void, c_int, c_int, c_int, C.POINTER(c_int),
                                      C.POINTER(c_int), C.POINTER(c_int)]),
+    "lsm_debug_lif_stamps": (c_int, [c_void, c_int]),
 }
 
 EXPORTED_SYMBOLS = tuple(_SIGS)

@@ -12,85 +12,114 @@
 namespace {
 
 // ---------------------------------------------------------------------------------------------
-// Gammatone spectrogram.  One lane = one (clip, channel): four cascaded second-order sections in
-// float64 evaluated like scipy.signal.lfilter (direct form II transposed), / gain, squared, then
-// per column the sequential ascending sum of nwin samples, / nwin, sqrt.  Up to NWIN_MAX
-// overlapping windows are live at once (nwin <= NWIN_MAX * hop); they sit in named registers
-// that shift by one at every hop boundary.  Serial in time, parallel over clips x channels:
-// bound by float64 VALU issue, not by memory (64 KB of audio per clip, read through L1/L2).
+// Gammatone spectrogram.  One lane = one channel, one wave = 64 channels of ONE clip, so the audio
+// sample is wave-uniform and arrives through scalar loads (8 samples per fetch, next chunk
+// requested before the current one is consumed).  Per sample: four cascaded second-order
+// sections in float64 evaluated like scipy.signal.lfilter (direct form II transposed), / gain,
+// squared, then per column the sequential ascending sum of nwin samples, / nwin, sqrt.  Up to
+// NWIN_MAX overlapping windows are live at once (nwin <= NWIN_MAX * hop); they sit in named
+// registers that shift by one at every hop boundary.  Serial in time, parallel over clips x
+// channels: bound by float64 VALU issue (~36 operations per sample), not by memory.
+//
+// Exactness notes.  (1) A2 == 0 for every channel of this filter design, so x*b2 is a signed zero
+// and z1 = x*b2 - y*a2 equals -(y*a2) up to the sign of an exact zero, which can never reach a
+// non-zero value downstream; B2ZERO drops that product.  (2) y/gain is evaluated as
+// q = y*r, q' = fma(fma(-q, gain, y), r, q) with r = RN(1/gain): Markstein's sequence returns the
+// correctly rounded quotient (= the IEEE division the reference performs) unless gain's significand
+// is all ones, which the host checks before choosing this path.
 // ---------------------------------------------------------------------------------------------
 constexpr int NWIN_MAX = 4;
 
+// NW = ceil(nwin / hop) windows are live at any sample.  In every hop block exactly one window
+// completes: the one of age NW-1, after sample number pos = nwin - (NW-1)*hop of the block.  So a
+// block is: [0, pos) with NW windows accumulating, finalise, [pos, hop) with NW-1, rotate.
+template <int NW, bool B2ZERO, bool FASTDIV>
 __global__ __launch_bounds__(64) void gammatone_kernel(
-    const float *__restrict__ audio, int n_clips, int n_samples, const double *__restrict__ coefs,
+    const float *__restrict__ audio, int n_samples, const double *__restrict__ coefs,
     int n_filters, int nwin, int hop, int ncols, double *__restrict__ spec_out,
     double *__restrict__ db_out)
 {
-    const long g = (long)blockIdx.x * 64 + threadIdx.x;
-    if (g >= (long)n_clips * n_filters) return;
-    const int b = (int)(g / n_filters);
-    const int ch = (int)(g - (long)b * n_filters);
+    const int chl = blockIdx.x * 64 + threadIdx.x;
+    const bool live = chl < n_filters;
+    const int ch = live ? chl : n_filters - 1;
+    const int b = blockIdx.y;
     const double *k = coefs + (size_t)ch * 10;
     const double a0 = k[6];
     const double b0 = k[0] / a0, b2 = k[5] / a0;
     const double b11 = k[1] / a0, b12 = k[2] / a0, b13 = k[3] / a0, b14 = k[4] / a0;
     const double a1 = k[7] / a0, a2 = k[8] / a0, gain = k[9];
-    const float *x = audio + (size_t)b * n_samples;
+    const double rgain = 1.0 / gain;
+    const float *__restrict__ x = audio + (size_t)b * n_samples;      // wave-uniform
 
     double z01 = 0, z11 = 0, z02 = 0, z12 = 0, z03 = 0, z13 = 0, z04 = 0, z14 = 0;
-    double win[NWIN_MAX];
+    double win[NW];
 #pragma unroll
-    for (int q = 0; q < NWIN_MAX; ++q) win[q] = 0.0;
+    for (int q = 0; q < NW; ++q) win[q] = 0.0;
 
+    auto filt = [&](float xf) -> double {
+        const double x0 = (double)xf;
+        const double y1 = z01 + b0 * x0;
+        z01 = (z11 + x0 * b11) - y1 * a1;
+        z11 = B2ZERO ? -(y1 * a2) : x0 * b2 - y1 * a2;
+        const double y2 = z02 + b0 * y1;
+        z02 = (z12 + y1 * b12) - y2 * a1;
+        z12 = B2ZERO ? -(y2 * a2) : y1 * b2 - y2 * a2;
+        const double y3 = z03 + b0 * y2;
+        z03 = (z13 + y2 * b13) - y3 * a1;
+        z13 = B2ZERO ? -(y3 * a2) : y2 * b2 - y3 * a2;
+        const double y4 = z04 + b0 * y3;
+        z04 = (z14 + y3 * b14) - y4 * a1;
+        z14 = B2ZERO ? -(y4 * a2) : y3 * b2 - y4 * a2;
+        double o;
+        if (FASTDIV) {
+            const double q0 = y4 * rgain;
+            o = __builtin_fma(__builtin_fma(-q0, gain, y4), rgain, q0);
+        } else {
+            o = y4 / gain;
+        }
+        return o * o;
+    };
+    // samples [n, n_to) with the NACT youngest windows accumulating
+#define LSM_RUN(n_to, NACT)                                                         \
+    {                                                                               \
+        for (; n + 8 <= (n_to); n += 8) {                                           \
+            float xs[8];                                                            \
+            _Pragma("unroll") for (int u = 0; u < 8; ++u) xs[u] = x[n + u];         \
+            _Pragma("unroll") for (int u = 0; u < 8; ++u) {                         \
+                const double e = filt(xs[u]);                                       \
+                _Pragma("unroll") for (int q = 0; q < (NACT); ++q) win[q] += e;     \
+            }                                                                       \
+        }                                                                           \
+        for (; n < (n_to); ++n) {                                                   \
+            const double e = filt(x[n]);                                            \
+            _Pragma("unroll") for (int q = 0; q < (NACT); ++q) win[q] += e;         \
+        }                                                                           \
+    }
+
+    const int pos = nwin - (NW - 1) * hop;               // in (0, hop]
     const int n_end = (ncols - 1) * hop + nwin;          // samples past this feed no column
-    const int n_blocks = (n_end + hop - 1) / hop;
     const double dn = (double)nwin;
-    for (int h = 0; h < n_blocks; ++h) {
-        // age q window started at block h - q and has nwin - q*hop samples left in this block
-        int len[NWIN_MAX];
-#pragma unroll
-        for (int q = 0; q < NWIN_MAX; ++q) {
-            const int left = nwin - q * hop;
-            len[q] = left < 0 ? 0 : (left < hop ? left : hop);
-        }
+    const size_t obase = ((size_t)b * n_filters + ch) * ncols;
+    int n = 0;
+    for (int h = 0; n < n_end; ++h) {
         const int base = h * hop;
-        const int lim = (n_end - base) < hop ? (n_end - base) : hop;
-        for (int i = 0; i < lim; ++i) {
-            const double x0 = (double)x[base + i];
-            const double y1 = z01 + b0 * x0;
-            z01 = (z11 + x0 * b11) - y1 * a1;
-            z11 = x0 * b2 - y1 * a2;
-            const double y2 = z02 + b0 * y1;
-            z02 = (z12 + y1 * b12) - y2 * a1;
-            z12 = y1 * b2 - y2 * a2;
-            const double y3 = z03 + b0 * y2;
-            z03 = (z13 + y2 * b13) - y3 * a1;
-            z13 = y2 * b2 - y3 * a2;
-            const double y4 = z04 + b0 * y3;
-            z04 = (z14 + y3 * b14) - y4 * a1;
-            z14 = y3 * b2 - y4 * a2;
-            const double o = y4 / gain;
-            const double e = o * o;
-#pragma unroll
-            for (int q = 0; q < NWIN_MAX; ++q)
-                if (i < len[q]) win[q] += e;
-        }
-        // windows that ended inside this block: age q ends here iff 0 < nwin - q*hop <= hop
-#pragma unroll
-        for (int q = 0; q < NWIN_MAX; ++q) {
-            const int left = nwin - q * hop;
-            const int c = h - q;
-            if (left > 0 && left <= hop && c >= 0 && c < ncols) {
-                const double y = sqrt(win[q] / dn);
-                const size_t o = ((size_t)b * n_filters + ch) * ncols + c;
-                if (spec_out) spec_out[o] = y;
-                if (db_out) db_out[o] = 20 * log10(y + 1e-9);
+        const int mid = min(base + pos, n_end);
+        LSM_RUN(mid, NW)
+        const int c = h - (NW - 1);                      // the column that just completed
+        if (n == base + pos && c >= 0 && c < ncols) {
+            const double y = sqrt(win[NW - 1] / dn);
+            if (live) {
+                if (spec_out) spec_out[obase + c] = y;
+                if (db_out) db_out[obase + c] = 20 * log10(y + 1e-9);
             }
         }
+        const int stop = min(base + hop, n_end);
+        LSM_RUN(stop, NW - 1)
 #pragma unroll
-        for (int q = NWIN_MAX - 1; q > 0; --q) win[q] = win[q - 1];
+        for (int q = NW - 1; q > 0; --q) win[q] = win[q - 1];
         win[0] = 0.0;
     }
+#undef LSM_RUN
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -259,8 +288,8 @@ int launch_spec_to_spikes(const T *db, int n_clips, int n_filters, int ncols, in
                           int apply_floor, const T *thr_on, const T *thr_off, int n_thr,
                           int redundancy, uint8_t *raster, T *norm_out, void *stream)
 {
-    LSM_REQUIRE(db != nullptr, "spec_to_spikes: null input");
     LSM_REQUIRE(n_clips >= 0 && n_filters >= 1 && ncols >= 2 && time_bins >= 2, "bad shape");
+    LSM_REQUIRE(db != nullptr || n_clips == 0, "spec_to_spikes: null input");
     LSM_REQUIRE(n_thr >= 0 && n_thr <= MAX_THR, "n_thr=%d outside [0, %d]", n_thr, MAX_THR);
     LSM_REQUIRE(redundancy >= 1, "redundancy must be >= 1");
     LSM_REQUIRE(n_thr == 0 || (thr_on && thr_off), "null threshold table");
@@ -286,9 +315,9 @@ template <typename T>
 int launch_encode(const T *spec, int n_rows, int n_bins, const T *thr_on, const T *thr_off,
                   int n_thr, uint8_t *out, void *stream)
 {
-    LSM_REQUIRE(spec && out && thr_on && thr_off, "encode: null buffer");
     LSM_REQUIRE(n_rows >= 0 && n_bins >= 1 && n_thr >= 1 && n_thr <= MAX_THR, "bad shape");
     if (n_rows == 0) return LSM_OK;
+    LSM_REQUIRE(spec && out && thr_on && thr_off, "encode: null buffer");
     SpikeArgs<T> a{};
     for (int q = 0; q < MAX_THR; ++q) { a.on[q] = q < n_thr ? thr_on[q] : (T)0; a.off[q] = q < n_thr ? thr_off[q] : (T)0; }
     hipLaunchKernelGGL(encode_kernel<T>, dim3((n_rows + 63) / 64), dim3(64), 0, (hipStream_t)stream,
@@ -303,20 +332,39 @@ int launch_encode(const T *spec, int n_rows, int n_bins, const T *thr_on, const 
 
 LSM_API int lsm_gammatone_spec_f64(const float *audio, int n_clips, int n_samples,
                                    const double *coefs, int n_filters, int nwin, int hop,
-                                   int ncols, double *spec_out, double *db_out, void *stream)
+                                   int ncols, double *spec_out, double *db_out, int coef_flags,
+                                   void *stream)
 {
+    LSM_REQUIRE(n_clips >= 0 && n_filters >= 1 && n_samples >= 1, "bad shape");
+    if (n_clips == 0) return LSM_OK;
     LSM_REQUIRE(audio && coefs, "gammatone: null input");
     LSM_REQUIRE(spec_out || db_out, "gammatone: both outputs null");
-    LSM_REQUIRE(n_clips >= 0 && n_filters >= 1 && n_samples >= 1, "bad shape");
     LSM_REQUIRE(nwin >= 1 && hop >= 1 && ncols >= 1, "bad window");
     LSM_REQUIRE(nwin <= NWIN_MAX * hop, "nwin=%d needs more than %d overlapping windows of hop=%d",
                 nwin, NWIN_MAX, hop);
     LSM_REQUIRE((long)(ncols - 1) * hop + nwin <= n_samples, "columns exceed the clip");
-    if (n_clips == 0) return LSM_OK;
-    const long lanes = (long)n_clips * n_filters;
-    hipLaunchKernelGGL(gammatone_kernel, dim3((unsigned)((lanes + 63) / 64)), dim3(64), 0,
-                       (hipStream_t)stream, audio, n_clips, n_samples, coefs, n_filters, nwin, hop,
-                       ncols, spec_out, db_out);
+    LSM_REQUIRE(n_clips <= 65535, "at most 65535 clips per call (grid.y)");
+    const dim3 grid((unsigned)((n_filters + 63) / 64), (unsigned)n_clips);
+    const bool fast = (coef_flags & 3) == 3;       // both properties verified by the host
+    const int nw = (nwin + hop - 1) / hop;
+#define LSM_GT(NW)                                                                            \
+    {                                                                                         \
+        if (fast)                                                                             \
+            hipLaunchKernelGGL((gammatone_kernel<NW, true, true>), grid, dim3(64), 0,         \
+                               (hipStream_t)stream, audio, n_samples, coefs, n_filters, nwin, \
+                               hop, ncols, spec_out, db_out);                                 \
+        else                                                                                  \
+            hipLaunchKernelGGL((gammatone_kernel<NW, false, false>), grid, dim3(64), 0,       \
+                               (hipStream_t)stream, audio, n_samples, coefs, n_filters, nwin, \
+                               hop, ncols, spec_out, db_out);                                 \
+    }
+    switch (nw) {
+    case 1: LSM_GT(1) break;
+    case 2: LSM_GT(2) break;
+    case 3: LSM_GT(3) break;
+    default: LSM_GT(4) break;
+    }
+#undef LSM_GT
     LSM_CHECK_HIP(hipGetLastError());
     return LSM_OK;
 }

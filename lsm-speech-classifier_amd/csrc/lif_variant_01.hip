@@ -1,0 +1,10 @@
+// LIF kernel instantiations with INREG=0, SEGLDS=1 (see lif_kernel.h); one translation unit
+// per combination so that the four build in parallel.
+#include "lif_kernel.h"
+
+namespace lsm_lif {
+lif_fn_t pick_lif_01(int sl, int wpc) { return pick_sl<false, true>(sl, wpc); }
+#if LSM_STAMP
+LSM_DEFINE_STAMP_READER(read_lif_stamps_01)
+#endif
+}  // namespace lsm_lif

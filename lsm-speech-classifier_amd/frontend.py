@@ -62,6 +62,20 @@ def gammatone_filter_table(fs: float, channels: int, f_min: float) -> np.ndarray
     return tab
 
 
+def coef_flags(tab: np.ndarray) -> int:
+    """Properties of a coefficient table that let the kernel skip work without changing a bit:
+    bit 0: every A2 is exactly zero; bit 1: no gain has an all-ones significand (the one case in
+    which the FMA division sequence is not guaranteed to round like a true division)."""
+    flags = 0
+    if not np.any(tab[:, 5]):
+        flags |= 1
+    mant = np.ascontiguousarray(tab[:, 9]).view(np.uint64) & np.uint64((1 << 52) - 1)
+    if np.all(np.isfinite(tab[:, 9])) and not np.any(mant == np.uint64((1 << 52) - 1)) \
+            and np.all(np.abs(tab[:, 9]) > 1e-200) and np.all(np.abs(tab[:, 9]) < 1e200):
+        flags |= 2
+    return flags
+
+
 def _round_half_away(x: float) -> int:
     return int(np.sign(x) * np.floor(np.abs(x) + 0.5))
 
@@ -117,6 +131,7 @@ class SpikeFrontEnd:
                                                              self.n_samples)
             tab = gammatone_filter_table(SAMPLE_RATE, self.n_filters, GT_F_MIN)
             self.coefs = torch.from_numpy(tab).to(self.device)
+            self.coef_flags = coef_flags(tab)
             self.dtype = torch.float64
         else:
             from . import mel as _mel
@@ -153,7 +168,7 @@ class SpikeFrontEnd:
         spec = torch.empty_like(db) if want_spec else None
         _lib.check(self.lib.lsm_gammatone_spec_f64(
             _dev(audio), B, self.n_samples, _dev(self.coefs), self.n_filters, self.nwin, self.hop,
-            self.ncols, _dev(spec) if want_spec else None, _dev(db), _stream()),
+            self.ncols, _dev(spec) if want_spec else None, _dev(db), self.coef_flags, _stream()),
             "lsm_gammatone_spec_f64")
         return db, spec
 

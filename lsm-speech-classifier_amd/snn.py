@@ -64,10 +64,13 @@ class SNN:
         self._features = None
 
     def __del__(self):
-        h = getattr(self, "_handle", None)
-        if h is not None and h.value:
-            self.lib.lsm_reservoir_destroy(h)
-            self._handle = C.c_void_p()
+        try:
+            h = getattr(self, "_handle", None)
+            if h is not None and h.value:
+                self.lib.lsm_reservoir_destroy(h)
+                self._handle = None
+        except Exception:          # interpreter shutdown: modules may already be torn down
+            pass
 
     # ---- batched path -------------------------------------------------------------------
     def run_batch(self, spikes, feature_keys=None, want_spike_matrix=False, want_v_trace=False,

@@ -224,6 +224,8 @@ ORC_API int orc_lif_run(int N, int C, int T,
 
     for (int t = 0; t < T; ++t) {
         for (int i = 0; i < N; ++i) {
+            /* SPEC.md §3: one float32 accumulator; presynaptic neurons ascending first, then
+             * input channels ascending */
             float cur = 0.0f;
             for (int e = csr_ptr[i]; e < csr_ptr[i + 1]; ++e)
                 cur += csr_w[e] * (float)s_prev[csr_pre[e]];
