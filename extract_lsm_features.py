@@ -1,0 +1,181 @@
+"""Stage 2 of the pipeline: spike-train dataset (File 1) -> LSM features (File 2).
+
+Drop-in for the reference script of the same name (same CLI flags, function names, constants and
+``lsm_features_larger.npz`` schema; /root/reference/extract_lsm_features.py).  The reservoir
+(third-party ``snnpy`` in the reference) is ``lsm_speech_classifier_amd.snn.SNN``: all clips of a
+split run through ONE batched HIP kernel launch instead of a per-clip Python loop; under
+``torchrun`` the clips shard across the GPUs of the node and the feature rows are all-gathered
+(RCCL).  There is no CPU fallback.
+"""
+import argparse
+from pathlib import Path
+
+import numpy as np
+
+NUM_NEURONS = 1000
+NUM_OUTPUT_NEURONS = 400
+LEAK_COEFFICIENT = 1 / 100
+REFRACTORY_PERIOD = 2
+MEMBRANE_THRESHOLD = 2.0
+SMALL_WORLD_P = 0.1
+SMALL_WORLD_K = int(0.10 * NUM_NEURONS * 2)
+WEIGHT_VARIANCE = 10
+DATASET_FILE = "speech_spike_dataset_pure_redundancy.npz"
+FEATURE_FILE = "lsm_features_larger.npz"
+RUN_BATCH = 4096             # clips per kernel launch
+
+_RATE = ['spike_counts', 'spike_variances', 'burst_counts']
+_TIMING = ['mean_spike_times', 'first_spike_times', 'last_spike_times']
+_RHYTHM = ['mean_isi', 'isi_variances']
+FEATURE_SETS = {
+    'all': ['spike_counts', 'spike_variances'] + _TIMING + _RHYTHM + ['burst_counts'],
+    'rate': _RATE,
+    'timing': _TIMING,
+    'rhythm': _RHYTHM,
+    'original': ['spike_counts', 'spike_variances', 'mean_spike_times'] + _RHYTHM,
+}
+
+np.random.seed(42)
+
+
+def calculate_theoretical_w_critico(lsm_params, input_data):
+    """Mean-field critical weight from the input spike density of the first <= 500 clips:
+    (theta - 2 * density * refractory) / (k / 2); 0.007 when there is no data or k == 0."""
+    head = input_data[:min(500, len(input_data))]
+    n_spikes = sum(int(np.sum(clip)) for clip in head)
+    n_cells = sum(int(clip.shape[0]) * int(clip.shape[1]) for clip in head)
+    if n_cells == 0:
+        return 0.007
+    density = n_spikes / n_cells
+    beta = lsm_params.small_world_graph_k / 2
+    if beta == 0:
+        return 0.007
+    w_critico = (lsm_params.membrane_threshold - 2 * density * lsm_params.refractory_period) / beta
+    print(f"Theoretical w_critico: {w_critico:.8f}")
+    return w_critico
+
+
+def load_spike_dataset(filename=DATASET_FILE):
+    if not Path(filename).exists():
+        print(f"Error: Dataset not found at '{filename}'")
+        return None, None
+    with np.load(filename) as data:
+        X_spikes, y_labels = data['X_spikes'], data['y_labels']
+    print(f"Loaded {len(X_spikes)} samples from '{filename}'")
+    return X_spikes, y_labels
+
+
+def extract_all_features(lsm, spike_data, feature_keys, desc=""):
+    """(n, C, T) uint8 -> (n, len(keys) * N_out) features, NaN -> 0, keys in the given order.
+    Batched on the GPU (and sharded across ranks under torchrun) when ``lsm`` offers ``run_batch``;
+    otherwise the reference's one-clip-at-a-time object protocol is used."""
+    if hasattr(lsm, "run_batch"):
+        import torch
+        from lsm_speech_classifier_amd import dist as lsm_dist
+        rank, _, world = lsm_dist.env_world()
+        n = len(spike_data)
+        lo, hi = lsm_dist.shard_range(n, rank, world) if world > 1 else (0, n)
+        if desc and rank == 0:
+            print(f"{desc}: {n} clips" + (f" over {world} GPUs" if world > 1 else ""))
+        rows = []
+        for a in range(lo, hi, RUN_BATCH):
+            feats, _, _ = lsm.run_batch(np.ascontiguousarray(spike_data[a:min(hi, a + RUN_BATCH)]),
+                                        feature_keys)
+            rows.append(feats)
+        n_feat = len([k for k in feature_keys]) * lsm.num_output_neurons
+        local = torch.cat(rows) if rows else torch.empty((0, n_feat), dtype=torch.float32,
+                                                         device=lsm.device)
+        return lsm_dist.gather_rows(local, n).cpu().numpy()
+    rows = []
+    for sample in spike_data:
+        lsm.reset()
+        lsm.set_input_spike_times(sample)
+        lsm.simulate()
+        feats = lsm.extract_features_from_spikes()
+        rows.append(np.concatenate([np.nan_to_num(feats[k].copy()) for k in feature_keys if k in feats]))
+    return np.array(rows)
+
+
+def run_network_diagnostics(lsm, X_sample_batch):
+    """Health check on the first 5 clips: share of neurons that fire at least once."""
+    print("\n" + "=" * 40 + "\nRUNNING NETWORK DIAGNOSTICS\n" + "=" * 40)
+    n_neurons = lsm.num_neurons
+    participation = []
+    for i, sample in enumerate(X_sample_batch[:5]):
+        lsm.reset()
+        lsm.set_input_spike_times(sample)
+        lsm.simulate()
+        spikes = getattr(lsm, "spike_matrix", None)
+        if spikes is None:
+            print("Warning: Cannot access internal spike matrix for diagnostics.")
+            return
+        per_neuron = np.sum(spikes, axis=0)
+        active = int(np.count_nonzero(per_neuron))
+        participation.append(active / n_neurons * 100)
+        print(f"Sample {i + 1}: Active: {participation[-1]:.1f}% | Dead: {n_neurons - active} | "
+              f"Avg Spikes/Neuron: {np.mean(per_neuron):.2f}")
+    avg = float(np.mean(participation)) if participation else 0.0
+    print("-" * 40 + f"\nDIAGNOSTIC RESULT:\n   Average Participation: {avg:.1f}%")
+    if avg < 40:
+        print("   STATUS: SUB-CRITICAL (Too Silent)\n   Recommendation: INCREASE multiplier or DECREASE threshold.")
+    elif avg > 98:
+        print("   STATUS: SUPER-CRITICAL (Epileptic/Saturated)\n   Recommendation: DECREASE multiplier.")
+    else:
+        print("   STATUS: EDGE OF CHAOS (Healthy)\n   (Ideal is 80-95% participation with low firing rates)")
+    print("=" * 40 + "\n")
+    return avg
+
+
+def main(feature_set: str, multiplier: float, leak_variance_divisor: float = None):
+    from sklearn.model_selection import train_test_split
+    from sklearn.preprocessing import StandardScaler
+    from lsm_speech_classifier_amd import dist as lsm_dist
+    from lsm_speech_classifier_amd.snn import SNN, SimulationParams
+
+    rank, _, world = lsm_dist.init()
+    X_spikes, y_labels = load_spike_dataset()
+    if X_spikes is None:
+        return
+    X_train, X_test, y_train, y_test = train_test_split(
+        X_spikes, y_labels, test_size=0.2, random_state=42, stratify=y_labels)
+
+    params = SimulationParams(
+        num_neurons=NUM_NEURONS, mean_weight=0.0, num_output_neurons=NUM_OUTPUT_NEURONS,
+        membrane_threshold=MEMBRANE_THRESHOLD, leak_coefficient=LEAK_COEFFICIENT,
+        refractory_period=REFRACTORY_PERIOD, small_world_graph_p=SMALL_WORLD_P,
+        small_world_graph_k=SMALL_WORLD_K, input_spike_times=X_train[0],
+        leak_variance_divisor=leak_variance_divisor)
+    optimal_weight = calculate_theoretical_w_critico(params, X_train) * multiplier
+    print(f"Using weight: {optimal_weight:.8f} (multiplier: {multiplier:.2f})")
+    if leak_variance_divisor:
+        print(f"Using Heterogeneous Leak. Divisor: {leak_variance_divisor}")
+    params.mean_weight = optimal_weight
+    params.weight_variance = WEIGHT_VARIANCE
+
+    lsm = SNN(simulation_params=params)       # every rank builds the same wiring (same seed)
+    if rank == 0:
+        run_network_diagnostics(lsm, X_train)
+
+    keys = FEATURE_SETS[feature_set]
+    print(f"Extracting feature set: '{feature_set}'")
+    X_train_feat = extract_all_features(lsm, X_train, keys, "Training")
+    X_test_feat = extract_all_features(lsm, X_test, keys, "Testing")
+    if rank != 0:
+        return
+
+    scaler = StandardScaler()
+    X_train_scaled = scaler.fit_transform(X_train_feat)
+    X_test_scaled = scaler.transform(X_test_feat)
+    np.savez_compressed(FEATURE_FILE, X_train_features=X_train_scaled, y_train=y_train,
+                        X_test_features=X_test_scaled, y_test=y_test, feature_set=feature_set,
+                        leak_variance_divisor=leak_variance_divisor)
+    print(f"Extraction complete. Features saved to '{FEATURE_FILE}'")
+
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser(description="Extract features from a spike train dataset using an LSM.")
+    ap.add_argument("--feature-set", type=str, default="original", choices=FEATURE_SETS.keys())
+    ap.add_argument("--multiplier", type=float, default=0.6)
+    ap.add_argument("--leak-variance-divisor", type=float, default=None)
+    a = ap.parse_args()
+    main(feature_set=a.feature_set, multiplier=a.multiplier, leak_variance_divisor=a.leak_variance_divisor)

@@ -1,0 +1,70 @@
+"""Clip sharding across the GPUs of one node + the one exchange step of the path.
+
+The reference is a single serial loop over clips (/root/reference/extract_lsm_features.py:78);
+clips are independent (``lsm.reset()`` precedes each one, :79), so they shard with no data-path
+collective: rank r takes the contiguous block [lo, hi) of the dataset (gather order = dataset
+order) and the fp32 feature rows are all-gathered once at the end (RCCL over xGMI through
+``torch.distributed``; ``gloo`` on CPU in the tests).  StandardScaler and the npz write stay on
+rank 0 so that results equal the single-process run exactly.
+"""
+from __future__ import annotations
+
+import os
+
+import torch
+import torch.distributed as dist
+
+
+def env_world():
+    """(rank, local_rank, world_size) from the torchrun environment (1 process when absent)."""
+    return (int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0")),
+            int(os.environ.get("WORLD_SIZE", "1")))
+
+
+def init(backend: str | None = None):
+    """Join the process group when launched under torchrun; no-op for a single process."""
+    rank, local_rank, world = env_world()
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        if backend == "nccl":
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group(backend, device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
+    return rank, local_rank, world
+
+
+def shard_bounds(n: int, world: int):
+    """Per-rank [lo, hi): contiguous blocks of ceil(n/world) clips (the last ones may be short or
+    empty)."""
+    per = -(-n // world) if world > 0 else n
+    return [(min(n, r * per), min(n, (r + 1) * per)) for r in range(world)]
+
+
+def shard_range(n: int, rank: int, world: int):
+    return shard_bounds(n, world)[rank]
+
+
+def gather_rows(local: torch.Tensor, n_total: int) -> torch.Tensor:
+    """All-gather the per-rank row blocks of ``shard_bounds`` back into dataset order.
+    ``local`` is (hi-lo, F) on this rank's device; every rank returns (n_total, F)."""
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return local
+    world = dist.get_world_size()
+    per = -(-n_total // world)
+    pad = torch.zeros((per, local.shape[1]), dtype=local.dtype, device=local.device)
+    pad[: local.shape[0]] = local
+    out = torch.empty((world * per, local.shape[1]), dtype=local.dtype, device=local.device)
+    dist.all_gather_into_tensor(out, pad)
+    return out[:n_total]
+
+
+def broadcast_float(value: float, src: int = 0, device=None) -> float:
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return value
+    t = torch.tensor([value], dtype=torch.float64, device=device)
+    dist.broadcast(t, src)
+    return float(t.item())

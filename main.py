@@ -1,0 +1,39 @@
+"""Run the three pipeline stages in order, each as its own Python process (like the reference's
+main.py, which shells out and ignores exit codes: /root/reference/main.py:19-27)."""
+import argparse
+import subprocess
+import sys
+
+STAGES = (
+    ("Step 1: Creating Spike Train Dataset",
+     lambda a: ["create_dataset.py", "--n-filters", str(a.n_filters), "--filterbank", a.filterbank]),
+    ("Step 2: Extracting LSM Features",
+     lambda a: ["extract_lsm_features.py", "--feature-set", a.feature_set, "--multiplier", str(a.multiplier)]),
+    ("Step 3: Training and Evaluating Classifier", lambda a: ["train_classifier.py"]),
+)
+
+
+def run_pipeline(n_filters: int, filterbank: str, feature_set: str, multiplier: float):
+    """1. spike-train dataset, 2. LSM features, 3. readout.  A failing stage does not stop the
+    next one (the reference discards exit codes too); it shows up as that stage's own message."""
+    args = argparse.Namespace(n_filters=n_filters, filterbank=filterbank, feature_set=feature_set,
+                              multiplier=multiplier)
+    print("--- Running Pipeline ---")
+    for title, command in STAGES:
+        print(f"\n--- {title} ---", flush=True)
+        subprocess.call([sys.executable] + command(args))
+    print("\n--- Pipeline Finished ---")
+
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser(description="Run the entire speech recognition pipeline.")
+    ap.add_argument("--n-filters", type=int, default=128, help="Number of filters for the filterbank.")
+    ap.add_argument("--filterbank", type=str, default="gammatone", choices=["mel", "gammatone"],
+                    help="Type of filterbank to use.")
+    ap.add_argument("--feature-set", type=str, default="original",
+                    choices=['all', 'rate', 'timing', 'rhythm', 'original'],
+                    help="The set of features to extract.")
+    ap.add_argument("--multiplier", type=float, default=0.6, help="Multiplier for w_critico.")
+    a = ap.parse_args()
+    run_pipeline(n_filters=a.n_filters, filterbank=a.filterbank, feature_set=a.feature_set,
+                 multiplier=a.multiplier)

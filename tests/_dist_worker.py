@@ -1,0 +1,40 @@
+"""Worker for tests/test_dist_gloo.py (one process per rank, gloo backend, CPU tensors)."""
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+class FakeLsm:
+    """Stands in for snn.SNN on a CPU box: 'features' are a deterministic function of the clip, so
+    the sharding/gather logic of extract_all_features can be checked without a GPU."""
+    device = torch.device("cpu")
+    num_output_neurons = 3
+
+    def run_batch(self, spikes, feature_keys):
+        x = torch.from_numpy(np.ascontiguousarray(spikes)).float()
+        base = torch.stack([x.sum(dim=(1, 2)), x[:, 0].sum(dim=1), x[:, :, 0].sum(dim=1)], dim=1)
+        return torch.cat([base * (k + 1) for k in range(len(feature_keys))], dim=1), None, None
+
+
+def main():
+    out_dir, n = sys.argv[1], int(sys.argv[2])
+    from lsm_speech_classifier_amd import dist as lsm_dist
+    import extract_lsm_features as ex
+    rank, _, world = lsm_dist.init("gloo")
+    rs = np.random.RandomState(1)
+    clips = (rs.rand(n, 4, 6) < 0.4).astype(np.uint8)
+    feats = ex.extract_all_features(FakeLsm(), clips, ["a", "b"], "")
+    lo, hi = lsm_dist.shard_range(n, rank, world)
+    w = lsm_dist.broadcast_float(3.25 + rank, 0)
+    np.savez(os.path.join(out_dir, f"rank{rank}.npz"), feats=feats, lo=lo, hi=hi, w=w)
+    torch.distributed.barrier()
+    torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

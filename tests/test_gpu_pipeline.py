@@ -1,0 +1,82 @@
+"""End-to-end on the GPU box: the three stage functions with the reference's signatures, File-1 /
+File-2 schemas, and equality of everything downstream with the CPU oracle on the same inputs
+(identical rasters => identical features => identical readout accuracy)."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def test_three_stages_match_oracle(tmp_path, monkeypatch, oracle_c, capsys):
+    import torch
+    assert torch.cuda.is_available()
+    import create_dataset as cd
+    import extract_lsm_features as ex
+    import train_classifier as tc
+    from lsm_speech_classifier_amd import reservoir as R, synth
+    from oracle import ref_numpy as O
+    from sklearn.model_selection import train_test_split
+    from sklearn.preprocessing import StandardScaler
+    monkeypatch.chdir(tmp_path)
+    words = ["yes", "no", "up", "visual"]
+    per_class = 20
+
+    # ---- stage 1 ----
+    cd.create_dataset(64, "gammatone", commands=words, synthetic_per_class=per_class)
+    with np.load(cd.OUTPUT_FILE) as d:
+        X, y = d["X_spikes"], d["y_labels"]
+    assert X.dtype == np.uint8 and X.shape == (len(words) * per_class, 64, 400)
+    assert y.dtype == np.int32 and list(np.unique(y)) == [0, 1, 2, 3]
+    audio = synth.class_chirps(np.repeat(np.arange(4), per_class), seed=1234)
+    coefs = O.gammatone_coefs(16000, 64, 50)
+    for b in (0, 17, 79):
+        ref = oracle_c.encode_hysteresis(oracle_c.normalise_resize(oracle_c.gammatone_db(
+            oracle_c.gammatone_spec(audio[b], coefs, 400, 160, 98))), cd.SPIKE_THRESHOLDS, cd.HYSTERESIS_GAP)
+        np.testing.assert_array_equal(X[b], ref)
+
+    # ---- stage 2 ----
+    ex.main("original", 0.6)
+    with np.load(ex.FEATURE_FILE, allow_pickle=True) as d:
+        Xtr, ytr, Xte, yte = d["X_train_features"], d["y_train"], d["X_test_features"], d["y_test"]
+        assert str(d["feature_set"]) == "original" and d["leak_variance_divisor"].item() is None
+    assert Xtr.shape == (64, 5 * ex.NUM_OUTPUT_NEURONS) and Xte.shape == (16, 5 * ex.NUM_OUTPUT_NEURONS)
+    assert ytr.dtype == np.int32
+    # the same split, reservoir and features through the oracle
+    X_train, X_test, y_train, y_test = train_test_split(X, y, test_size=0.2, random_state=42, stratify=y)
+    np.testing.assert_array_equal(y_train, ytr)
+    p = R.SimulationParams(num_neurons=ex.NUM_NEURONS, num_output_neurons=ex.NUM_OUTPUT_NEURONS,
+                           small_world_graph_k=ex.SMALL_WORLD_K)
+    p.mean_weight = O.w_critico(ex.SMALL_WORLD_K, 2.0, 2, X_train) * 0.6
+    res = R.build_reservoir(p, 64)
+    keys = ex.FEATURE_SETS["original"]
+    f_train = oracle_c.lif_run_batch(res, X_train, keys, n_threads=os.cpu_count() or 1)
+    f_test = oracle_c.lif_run_batch(res, X_test, keys, n_threads=os.cpu_count() or 1)
+    sc = StandardScaler()
+    np.testing.assert_array_equal(sc.fit_transform(f_train), Xtr)
+    np.testing.assert_array_equal(sc.transform(f_test), Xte)
+    assert f_train[:, :ex.NUM_OUTPUT_NEURONS].sum() > 0
+
+    # ---- stage 3 ----
+    acc = tc.train_and_evaluate_classifier()
+    assert acc is not None and 0.0 <= acc <= 1.0
+    out = capsys.readouterr().out
+    assert "DIAGNOSTIC RESULT" in out and "Test Accuracy" in out
+
+
+def test_diagnostics_band_on_speech_like_input():
+    """The reference's only behavioural pin (extract_lsm_features.py:143-151): 40-98 % average
+    participation over 5 clips = healthy.  SPEC.md fixes the input weight so that synthetic
+    speech-like clips at the default parameters land in that band."""
+    import extract_lsm_features as ex
+    from lsm_speech_classifier_amd import frontend, synth
+    from lsm_speech_classifier_amd.snn import SNN, SimulationParams
+    audio = synth.class_chirps(np.arange(24) % 12, seed=1234)
+    rasters = frontend.SpikeFrontEnd(128, "gammatone").encode(audio).cpu().numpy()
+    p = SimulationParams(num_neurons=1000, num_output_neurons=400, small_world_graph_k=200,
+                         input_spike_times=rasters[0])
+    p.mean_weight = ex.calculate_theoretical_w_critico(p, rasters) * 0.6
+    p.weight_variance = 10
+    avg = ex.run_network_diagnostics(SNN(simulation_params=p), rasters)
+    assert 40.0 <= avg <= 98.0

@@ -1,0 +1,57 @@
+"""Stage 3 of the pipeline: LSM features (File 2) -> linear readout, accuracy and report.
+
+Drop-in for the reference script of the same name (/root/reference/train_classifier.py): the
+readout stays a host-side multinomial logistic regression, as BASELINE.json's north_star asks.
+"""
+import inspect
+from pathlib import Path
+
+import numpy as np
+
+CLASS_NAMES = ["yes", "no", "up", "visual", "backward", "stop", "bird", "cat", "nine", "eight",
+               "zero", "follow"]
+FEATURE_FILE = "lsm_features_larger.npz"
+
+
+def _readout():
+    from sklearn.linear_model import LogisticRegression
+    kw = dict(random_state=42, max_iter=1000)
+    # `multi_class` is deprecated from scikit-learn 1.5 (multinomial is what lbfgs does anyway)
+    # and gone in 1.8: pass it only where it is still a silent, accepted argument.
+    import sklearn
+    major, minor = (int(p) for p in sklearn.__version__.split(".")[:2])
+    if "multi_class" in inspect.signature(LogisticRegression).parameters and (major, minor) < (1, 5):
+        kw["multi_class"] = "multinomial"
+    return LogisticRegression(**kw)
+
+
+def train_and_evaluate_classifier():
+    from sklearn.metrics import accuracy_score, classification_report
+    if not Path(FEATURE_FILE).exists():
+        print("Error: Dataset file not found. Please run 'extract_lsm_features.py' first.")
+        return
+    with np.load(FEATURE_FILE, allow_pickle=True) as data:
+        X_train, y_train = data['X_train_features'], data['y_train']
+        X_test, y_test = data['X_test_features'], data['y_test']
+    print(f"Loaded {len(X_train)} training and {len(X_test)} test samples.")
+
+    print("Training the Logistic Regression classifier...")
+    clf = _readout()
+    clf.fit(X_train, y_train)
+    print("Training complete.")
+
+    print("Evaluating performance on the test set...")
+    y_pred = clf.predict(X_test)
+    accuracy = accuracy_score(y_test, y_pred)
+    present = sorted(set(np.unique(y_train)) | set(np.unique(y_test)))
+    names = [CLASS_NAMES[i] if i < len(CLASS_NAMES) else f"class_{i}" for i in present]
+    report = classification_report(y_test, y_pred, labels=present, target_names=names, zero_division=0)
+    print("\n--- Final Results ---")
+    print(f"Test Accuracy: {accuracy * 100:.2f}%\n")
+    print("Classification Report:")
+    print(report)
+    return accuracy
+
+
+if __name__ == "__main__":
+    train_and_evaluate_classifier()
