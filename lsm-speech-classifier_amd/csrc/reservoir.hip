@@ -200,20 +200,23 @@ static size_t lif_lds_bytes(const lsm_reservoir *h, const Variant &v, int T)
     return lif_lds_core(h, v, T) + (lif_seg_in_lds(h, v, T) ? lif_seg_bytes(h, v) : 0);
 }
 
-// Pick the waves-per-clip layout: enough wavefronts to cover the chip's 1024 SIMDs about twice,
-// among the layouts this reservoir supports and whose LDS image fits one CU.
+// Pick the waves-per-clip layout.  Measured on MI355X at N=1000 (profiles/): the best layout has
+// about 4096 wavefronts in flight (B=256 -> 16, B=512 -> 8) and never fewer than 4 waves per clip
+// (B=4096: 4 waves 9.1 ms, 2 waves 10.6 ms, 1 wave 17.6 ms).  Among the layouts this reservoir
+// supports and whose LDS image fits one CU, take the smallest one at or above that target.
 static const Variant *choose_variant(const lsm_reservoir *h, int B, int T, int requested)
 {
-    const Variant *best = nullptr;
     if (requested > 0) {
         for (const auto &v : h->var)
             if (v.wpc == requested && lif_lds_bytes(h, v, T) <= 160 * 1024) return &v;
         return nullptr;
     }
+    int target = 4;
+    while (target < 16 && (long)B * target < 4096) target <<= 1;
+    const Variant *best = nullptr;
     for (const auto &v : h->var) {
         if (!v.wpc || lif_lds_bytes(h, v, T) > 160 * 1024) continue;
-        if (!best) { best = &v; continue; }
-        if ((long)B * best->wpc < 2048) best = &v;       // keep widening while the chip is underfilled
+        if (!best || best->wpc < target) best = &v;      // keep widening until the target is met
     }
     return best;
 }
