@@ -112,6 +112,8 @@ def main():
     ap.add_argument("--waves-per-clip", type=int, default=0)
     ap.add_argument("--stage", default="full", choices=["full", "reservoir", "frontend"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--streams", type=int, default=3,
+                    help="HIP streams the steps rotate over (consecutive steps overlap; 1 = serial)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -150,8 +152,21 @@ def main():
     lay = net.layout(B, fe.n_steps, args.waves_per_clip)
 
     ev_pairs = []
+    n_streams = max(1, args.streams)
+    streams = [torch.cuda.Stream(device=dev) for _ in range(n_streams)] if n_streams > 1 else [None]
+    step_no = [0]
 
     def step(timed):
+        """One pass of the hot path over the batch, issued on the next stream of the rotation: the
+        work of a step is ordered on its own stream, consecutive steps overlap on the GPU."""
+        st = streams[step_no[0] % n_streams]
+        step_no[0] += 1
+        if st is None:
+            return one_step(timed)
+        with torch.cuda.stream(st):
+            return one_step(timed)
+
+    def one_step(timed):
         if args.stage == "reservoir":
             rasters = rasters0
         else:
@@ -176,6 +191,9 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
+    for st in streams:                 # inputs were produced on the default stream
+        if st is not None:
+            st.wait_stream(torch.cuda.current_stream())
     for _ in range(args.warmup):
         out = step(False)
     fence()
@@ -209,6 +227,7 @@ def main():
                        "small_world_k": cfg["k"], "num_output_neurons": cfg["n_out"],
                        "time_steps": fe.n_steps, "feature_set": "original",
                        "waves_per_clip": lay["waves_per_clip"], "lds_bytes_per_clip": lay["lds_bytes"],
+                       "streams": n_streams,
                        "mean_output_spikes_per_clip": spikes_per_clip,
                        "sharding": f"clips x{world}, feature all-gather" if world > 1 else "single GPU"},
         }

@@ -68,6 +68,22 @@ int lsm_spec_to_spikes_f32(const float *db, int n_clips, int n_filters, int ncol
                            int apply_floor, const float *thr_on, const float *thr_off, int n_thr,
                            int redundancy, uint8_t *raster, float *norm_out, void *stream);
 
+/* Replaces librosa.feature.melspectrogram(y, sr=16000, n_mels, hop_length) as called at
+ * create_dataset.py:44-47 (n_fft must be 2048, librosa's default): centred zero-padded frames,
+ * float64 window x float32 frame, float64 FFT stored as complex64, |.|^2 in float32, mel basis.
+ *   window_dev (n_fft) f64, twiddle_dev (n_fft/2, 2) f64 {cos, -sin}, basis_dev (n_mels, n_fft/2+1)
+ *   f32, lo_dev/hi_dev (n_mels) i32 non-zero bin range of each filter: DEVICE tables built by the host
+ *   power_out (n_clips, n_mels, n_frames) float32, n_frames = 1 + n_samples / hop */
+int lsm_mel_power_f32(const float *audio, int n_clips, int n_samples, int n_fft, int hop,
+                      int n_frames, const double *window_dev, const double *twiddle_dev,
+                      const float *basis_dev, const int32_t *lo_dev, const int32_t *hi_dev,
+                      int n_mels, float *power_out, void *stream);
+
+/* Replaces librosa.power_to_db(S, ref=np.max) (create_dataset.py:48) per clip, float32:
+ * 10*log10(max(amin, S)) - 10*log10(max(amin, max S)), floored at -top_db. */
+int lsm_power_to_db_f32(const float *power, int n_clips, int n_per_clip, float amin, float top_db,
+                        float *db_out, void *stream);
+
 /* Replaces convert_spectrogram_to_spikes_hysteresis (create_dataset.py:81-98) on an already
  * normalised spectrogram: spec (n_rows, n_bins) -> out (n_rows, n_bins*n_thr) uint8. */
 int lsm_encode_hysteresis_f64(const double *spec, int n_rows, int n_bins, const double *thr_on,

@@ -23,6 +23,9 @@ _SIGS = {
                                        c_int, c_int, c_void, c_void, c_void]),
     "lsm_spec_to_spikes_f32": (c_int, [c_void, c_int, c_int, c_int, c_int, c_int, c_void, c_void,
                                        c_int, c_int, c_void, c_void, c_void]),
+    "lsm_mel_power_f32": (c_int, [c_void, c_int, c_int, c_int, c_int, c_int, c_void, c_void, c_void,
+                                  c_void, c_void, c_int, c_void, c_void]),
+    "lsm_power_to_db_f32": (c_int, [c_void, c_int, c_int, c_float, c_float, c_void, c_void]),
     "lsm_encode_hysteresis_f64": (c_int, [c_void, c_int, c_int, c_void, c_void, c_int, c_void, c_void]),
     "lsm_encode_hysteresis_f32": (c_int, [c_void, c_int, c_int, c_void, c_void, c_int, c_void, c_void]),
     "lsm_reservoir_create": (c_int, [C.POINTER(c_void), c_int, c_int, c_void, c_void, c_void, c_void,

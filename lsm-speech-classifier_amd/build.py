@@ -7,7 +7,7 @@ import subprocess
 
 PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(PKG_DIR)
-SOURCES = ["lsm_api.hip", "frontend.hip", "reservoir.hip", "lif_variant_00.hip", "lif_variant_01.hip",
+SOURCES = ["lsm_api.hip", "frontend.hip", "mel.hip", "reservoir.hip", "lif_variant_00.hip", "lif_variant_01.hip",
            "lif_variant_10.hip", "lif_variant_11.hip"]
 HEADERS = ["lsm_common.h", "lif_kernel.h"]
 LIB_NAME = "liblsm_hip.so"

@@ -1,0 +1,72 @@
+"""Mel branch on the GPU vs the NumPy restatement of librosa's defaults (oracle/ref_numpy.py).
+Floating point with an FFT inside: the tolerance is stated per quantity; everything after the dB
+array (normalise, resize, encoder) is bit-exact on identical input (tests/test_gpu_parity.py)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+THR = [0.70, 0.80, 0.90, 0.95]
+
+
+def _audio(n, seed):
+    from lsm_speech_classifier_amd import synth
+    a = synth.class_chirps(list(range(n)), seed=seed)
+    a[n // 2:] = synth.white_noise(n - n // 2, seed=seed + 1)
+    return a
+
+
+@pytest.mark.parametrize("n_mels", [40, 128])
+def test_mel_frontend_matches_oracle(n_mels):
+    import torch
+    from lsm_speech_classifier_amd import frontend
+    from oracle import ref_numpy as O
+    audio = _audio(4, seed=n_mels)
+    fe = frontend.SpikeFrontEnd(n_mels, "mel")
+    assert fe.ncols == 101 and fe._mel.hop == 160
+    dev = torch.from_numpy(audio).cuda()
+    power = fe._mel.power(dev).cpu().numpy()
+    db, _ = fe.spectrogram_db(audio)
+    raster, norm = fe.spikes_from_db(db, want_norm=True)
+    db, norm, raster = db.cpu().numpy(), norm.cpu().numpy(), raster.cpu().numpy()
+    assert db.dtype == np.float32 and db.shape == (4, n_mels, 101)
+    flips = 0
+    for b in range(4):
+        p_ref = O.mel_power(audio[b], n_mels)
+        # float64 FFT on both sides, float32 power and projection
+        np.testing.assert_allclose(power[b], p_ref, rtol=1e-5, atol=2e-6 * p_ref.max())   # measured 2e-7
+        d_ref = O.power_to_db(p_ref)
+        np.testing.assert_allclose(db[b], d_ref, rtol=0, atol=1e-4)          # dB; measured 6e-6
+        n_ref = O.normalise_resize(d_ref)
+        np.testing.assert_allclose(norm[b], n_ref, rtol=0, atol=5e-6)       # measured 2.4e-7
+        # the encoder on the GPU's own normalised spectrogram is exact ...
+        np.testing.assert_array_equal(raster[b], O.encode_hysteresis(norm[b], THR, 0.1))
+        # ... and against the oracle's raster only threshold ties may flip
+        flips += int((raster[b] != O.encode_hysteresis(n_ref, THR, 0.1)).sum())
+    assert flips <= 4 * n_mels * 400 * 1e-4              # measured 0
+
+
+def test_cfg1_shape_end_to_end(oracle_c):
+    """BASELINE.json configs[0] shape: 40 mel filters, 500-neuron reservoir, through both stages;
+    the reservoir part must equal the oracle bit for bit on the GPU's own rasters."""
+    from lsm_speech_classifier_amd import frontend, reservoir as R, snn, synth
+    from oracle import ref_numpy as O
+    audio = synth.class_chirps(np.arange(8) % 4, seed=3)
+    rasters = frontend.SpikeFrontEnd(40, "mel").encode(audio).cpu().numpy()
+    assert rasters.shape == (8, 40, 400) and rasters.any()
+    p = R.SimulationParams(num_neurons=500, num_output_neurons=200, small_world_graph_k=100)
+    p.mean_weight = O.w_critico(100, 2.0, 2, rasters) * 0.6
+    res = R.build_reservoir(p, 40)
+    net = snn.SNN(p, reservoir=res)
+    feats, _, _ = net.run_batch(rasters, ["spike_counts", "mean_isi", "burst_counts"])
+    ref = oracle_c.lif_run_batch(res, rasters, ["spike_counts", "mean_isi", "burst_counts"], n_threads=8)
+    np.testing.assert_array_equal(feats.cpu().numpy(), ref)
+
+
+def test_audio_to_spectrogram_mel_single_clip():
+    from lsm_speech_classifier_amd import frontend
+    from oracle import ref_numpy as O
+    audio = _audio(2, seed=9)[0]
+    out = frontend.audio_to_spectrogram(audio, 40, "mel")
+    assert out.shape == (40, 100) and out.dtype == np.float32
+    np.testing.assert_allclose(out, O.normalise_resize(O.mel_db(audio, 40)), rtol=0, atol=5e-5)
