@@ -55,7 +55,7 @@ namespace { __device__ unsigned long long g_lif_stamps[8]; }   // one copy per t
 #define STAMP(k) do { } while (0)
 #endif
 
-constexpr int IN_REG_SLOTS = 4;       // input-map entries per lane kept in registers
+constexpr int IN_REG_SLOTS = 6;       // input-map entries per lane kept in registers
 constexpr int SPIKE_GROUP = 8;        // spiking neurons whose synapse loads are in flight together
 constexpr int IN_UNROLL = 4;          // input hits per neuron and step applied without a loop
 
@@ -89,7 +89,8 @@ __device__ __forceinline__ int lane_rank(unsigned long long mask)
                                           __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
 }
 
-// INREG: the wave's input-map entries fit IN_REG_SLOTS registers per lane (else read from LDS).
+// INREG: the wave's input-map entries fit IN_REG_SLOTS registers per lane (else they are streamed
+// from global memory every step: static addresses, L2-resident).
 // SEGLDS: the segment table is staged in LDS (else read from global memory).  Both are template
 // parameters so that every access keeps its own address space: a run-time choice between an LDS
 // and a global pointer compiles to flat loads, whose waits serialise the row loads behind them.
@@ -107,8 +108,7 @@ __global__ __launch_bounds__(WPC * 64) void lif_kernel(const LifArgs a)
     uint32_t *wcnt = reinterpret_cast<uint32_t *>(wlist + 2 * NPAD);                  // 2*16
     uint4 *feat = reinterpret_cast<uint4 *>(wcnt + 32);                               // n_out
     uint32_t *bits = reinterpret_cast<uint32_t *>(feat + a.n_out);                    // T*CW
-    uint32_t *in_ent = bits + a.T * a.CW;                                             // WPC*EinW (if !INREG)
-    uint32_t *lseg = in_ent + (INREG ? 0 : WPC * a.EinW);                             // N*WPC+1 (if seg_in_lds)
+    uint32_t *lseg = bits + a.T * a.CW;                                               // N*WPC+1 (if SEGLDS)
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -121,8 +121,6 @@ __global__ __launch_bounds__(WPC * 64) void lif_kernel(const LifArgs a)
     if (tid < 32) wcnt[tid] = 0u;
     for (int i = tid; i < a.n_out; i += NT) feat[i] = make_uint4(0, 0, 0, 0);
     for (int i = tid; i < T * CW; i += NT) bits[i] = 0u;
-    if (!INREG)
-        for (int i = tid; i < WPC * a.EinW; i += NT) in_ent[i] = a.in_ent[i];
     if (SEGLDS)
         for (int i = tid; i < N * WPC + 1; i += NT) lseg[i] = a.seg[i];
     __syncthreads();
@@ -178,7 +176,7 @@ __global__ __launch_bounds__(WPC * 64) void lif_kernel(const LifArgs a)
         }
     }
     const float theta = a.theta, w_in = a.w_in;
-    const uint32_t *my_ent = in_ent + w * a.EinW;
+    const uint32_t *my_ent = a.in_ent + (size_t)w * a.EinW;   // !INREG: streamed from L2 each step
     const bool trace = a.spike_matrix != nullptr || a.v_trace != nullptr;
     __syncthreads();
 

@@ -180,8 +180,7 @@ static size_t lif_lds_core(const lsm_reservoir *h, const Variant &v, int T)
 {
     const size_t npad = (size_t)v.sl * 64 * v.wpc;
     const size_t cw = (size_t)(h->C + 31) / 32;
-    return npad * 4 + npad * 4 + 2 * npad * 2 + 128 + (size_t)h->n_out * 16 + (size_t)T * cw * 4 +
-           (lif_inreg(v) ? 0 : (size_t)v.wpc * v.einw * 4);
+    return npad * 4 + npad * 4 + 2 * npad * 2 + 128 + (size_t)h->n_out * 16 + (size_t)T * cw * 4;
 }
 
 static size_t lif_seg_bytes(const lsm_reservoir *h, const Variant &v)
@@ -213,10 +212,12 @@ static const Variant *choose_variant(const lsm_reservoir *h, int B, int T, int r
     }
     int target = 4;
     while (target < 16 && (long)B * target < 4096) target <<= 1;
+    // large reservoirs: more waves per clip keep the per-lane neuron slots (registers, update work per
+    // wave) small -- N=4000, B=1024: 4 waves 68 ms, 8 waves 43 ms, 16 waves 26 ms
     const Variant *best = nullptr;
     for (const auto &v : h->var) {
         if (!v.wpc || lif_lds_bytes(h, v, T) > 160 * 1024) continue;
-        if (!best || best->wpc < target) best = &v;      // keep widening until the target is met
+        if (!best || best->wpc < target || best->sl > 4) best = &v;
     }
     return best;
 }

@@ -243,3 +243,19 @@ def test_full_size_properties(torch_cuda, oracle_c):
         np.testing.assert_array_equal(fw.cpu().numpy(), f)
     ref = oracle_c.lif_run_batch(res, rasters[:6], n_threads=6)
     np.testing.assert_array_equal(f[:6], ref)
+
+
+@pytest.mark.parametrize("n,k,n_out,c,clips", [(4000, 800, 1600, 128, 2), (8000, 1600, 3200, 256, 1)])
+def test_large_reservoirs_match_oracle(torch_cuda, oracle_c, n, k, n_out, c, clips):
+    """BASELINE.json configs[3]/[4] shapes (W no longer fits L2): parity spot check on a few clips,
+    default layout and one explicit layout."""
+    from lsm_speech_classifier_amd import snn, synth
+    rasters = synth.bernoulli_raster(clips, c, 400, 0.25, seed=n)
+    res = _reservoir(n, k, n_out, c, rasters)
+    net = snn.SNN(None, reservoir=res)
+    keys = ["spike_counts", "spike_variances", "mean_spike_times", "mean_isi", "isi_variances"]
+    ref = oracle_c.lif_run_batch(res, rasters, keys, n_threads=clips)
+    assert ref[:, :n_out].sum() > 0
+    for wpc in (0, 8):
+        feats, _, _ = net.run_batch(rasters, keys, waves_per_clip=wpc)
+        np.testing.assert_array_equal(feats.cpu().numpy(), ref)
