@@ -16,7 +16,8 @@
 //      prefix in scalar registers and lane l picks the l-th spiking neuron of the whole clip
 //      (wave order x rank = ascending j) with a compare chain -- no bit scanning, no loop;
 //   b. ONE LDS read fetches each listed neuron's segment bounds (LDS-resident table when it
-//      fits) and the synapse entries {target, weight} of up to 8 spiking neurons are loaded at
+//      fits); a ballot keeps only the neurons with synapses onto this wave's targets (at 16 waves per
+//      clip three quarters of the segments are empty) and the synapse entries {target, weight} of up to 8 spiking neurons are loaded at
 //      once from the CSC copy of W (L2-resident at N=1000), through nested "one more?" tests so
 //      that a group of n <= 8 costs one taken branch;
 //   c. while those loads fly, the input drive of step t is COUNTED: every (channel -> target)
@@ -27,8 +28,8 @@
 //      neuron are distinct, and LDS executes a wave's instructions in order, so this is the
 //      oracle's per-target sum "presynaptic j ascending" with only its zero terms skipped --
 //      bit-identical in fp32;
-//   e. update from registers: current = LDS sum, then + w_in count[target] times (SPEC.md §3:
-//      inputs after the recurrent terms; equal addends, so their mutual order cannot matter),
+//   e. update from registers: current = LDS sum + w_in * count[target] (SPEC.md §3: the input term
+//      comes after the recurrent terms),
 //      leak/integrate/threshold/reset/refractory by select, spike lists + feature accumulators
 //      (LDS) touched only inside one "any lane of this wave fired" branch; one barrier.
 // No MFMA: the update is sparse and integer/byte dominated.
@@ -57,7 +58,6 @@ namespace { __device__ unsigned long long g_lif_stamps[8]; }   // one copy per t
 
 constexpr int IN_REG_SLOTS = 6;       // input-map entries per lane kept in registers
 constexpr int SPIKE_GROUP = 8;        // spiking neurons whose synapse loads are in flight together
-constexpr int IN_UNROLL = 4;          // input hits per neuron and step applied without a loop
 
 struct LifArgs {
     int N, C, T, B;
@@ -65,6 +65,8 @@ struct LifArgs {
     float theta, w_in;
     const uint8_t *raster;     // (B, C, T) uint8
     const uint32_t *seg;       // (N*WPC + 1) begin offsets into syn, row-major (neuron, wave)
+    const uint32_t *rowptr;    // (N + 1) first synapse of each presynaptic neuron (= CSC pointer)
+    const uint16_t *segoff;    // (N, WPC + 1) segment starts relative to rowptr[j]; [WPC] = row length
     const uint2 *syn;          // CSC entries {target neuron, weight bits}
     const float *leak;         // (NPAD)
     const int *oslot;          // (NPAD) output slot or -1
@@ -108,7 +110,8 @@ __global__ __launch_bounds__(WPC * 64) void lif_kernel(const LifArgs a)
     uint32_t *wcnt = reinterpret_cast<uint32_t *>(wlist + 2 * NPAD);                  // 2*16
     uint4 *feat = reinterpret_cast<uint4 *>(wcnt + 32);                               // n_out
     uint32_t *bits = reinterpret_cast<uint32_t *>(feat + a.n_out);                    // T*CW
-    uint32_t *lseg = bits + a.T * a.CW;                                               // N*WPC+1 (if SEGLDS)
+    uint32_t *lrow = bits + a.T * a.CW;                                               // N+1 (if SEGLDS)
+    uint16_t *lso = reinterpret_cast<uint16_t *>(lrow + (a.N + 1));                     // N*(WPC+1) (if SEGLDS)
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -121,8 +124,12 @@ __global__ __launch_bounds__(WPC * 64) void lif_kernel(const LifArgs a)
     if (tid < 32) wcnt[tid] = 0u;
     for (int i = tid; i < a.n_out; i += NT) feat[i] = make_uint4(0, 0, 0, 0);
     for (int i = tid; i < T * CW; i += NT) bits[i] = 0u;
-    if (SEGLDS)
-        for (int i = tid; i < N * WPC + 1; i += NT) lseg[i] = a.seg[i];
+    if (SEGLDS) {
+        for (int i = tid; i < N + 1; i += NT) lrow[i] = a.rowptr[i];
+        const uint32_t *so32 = reinterpret_cast<const uint32_t *>(a.segoff);
+        uint32_t *lso32 = reinterpret_cast<uint32_t *>(lso);
+        for (int i = tid; i < (N * (WPC + 1) + 1) / 2; i += NT) lso32[i] = so32[i];
+    }
     __syncthreads();
     {
         const uint8_t *clip = a.raster + (size_t)b * a.C * T;
@@ -236,20 +243,34 @@ __global__ __launch_bounds__(WPC * 64) void lif_kernel(const LifArgs a)
             if (l < total) {
                 const int j = list_prev[wsel * NPW + (l - pbase)];
                 const int idx = j * WPC + w;
-                if (SEGLDS) { beg = lseg[idx]; end = lseg[idx + 1]; }
-                else { beg = a.seg[idx]; end = a.seg[idx + 1]; }
+                if (SEGLDS) {
+                    const uint32_t rp = lrow[j];
+                    const int io = j * (WPC + 1) + w;
+                    beg = rp + lso[io];
+                    end = rp + lso[io + 1];
+                } else {
+                    beg = a.seg[idx];
+                    end = a.seg[idx + 1];
+                }
             }
-            const int nb = (int)min(total - l0, 64u);
-            for (int s0 = 0; s0 < nb; s0 += SPIKE_GROUP) {
-                // ---- b. up to 8 rows in flight; slot k holds spike s0 + k.  Nested "more?" tests:
-                //         the group costs one taken branch (at its end), not one per slot ----
-                const int n8 = min(nb - s0, SPIKE_GROUP);
+            // only the listed neurons with at least one synapse onto THIS wave's targets matter here
+            unsigned long long todo = __ballot(beg < end);
+            while (todo != 0ull) {
+                // ---- b. up to 8 rows in flight, ascending list position.  Nested "one more?" tests:
+                //         a group costs one taken branch (at its end), not one per slot ----
+                const int n8 = min((int)__popcll(todo), SPIKE_GROUP);
                 uint32_t gb[SPIKE_GROUP], ge[SPIKE_GROUP];
                 uint2 ent[SPIKE_GROUP];
+                bool any_long = false;
 #define LSM_LD(k)                                                                   \
-    gb[k] = __builtin_amdgcn_readlane(beg, s0 + (k));                               \
-    ge[k] = __builtin_amdgcn_readlane(end, s0 + (k));                               \
-    if (gb[k] + lane < ge[k]) ent[k] = a.syn[gb[k] + lane];
+    {                                                                               \
+        const int sk = __builtin_ctzll(todo);                                       \
+        todo &= todo - 1ull;                                                        \
+        gb[k] = __builtin_amdgcn_readlane(beg, sk);                                 \
+        ge[k] = __builtin_amdgcn_readlane(end, sk);                                 \
+        any_long |= (ge[k] - gb[k]) > 64u;                                          \
+        if (gb[k] + lane < ge[k]) ent[k] = a.syn[gb[k] + lane];                     \
+    }
                 LSM_LD(0)
                 if (n8 > 1) { LSM_LD(1)
                 if (n8 > 2) { LSM_LD(2)
@@ -268,24 +289,38 @@ __global__ __launch_bounds__(WPC * 64) void lif_kernel(const LifArgs a)
                 // ---- d. ordered read+add+write, one spiking neuron after the other ----
 #define LSM_RMW(k)                                                                  \
     if (gb[k] + lane < ge[k]) acc[ent[k].x] = acc[ent[k].x] + __uint_as_float(ent[k].y); \
-    if (ge[k] - gb[k] > 64u)                                                        \
-        for (uint32_t base = gb[k] + 64u; base < ge[k]; base += 64u) {              \
-            __builtin_amdgcn_wave_barrier();                                        \
-            if (base + lane < ge[k]) {                                              \
-                const uint2 x = a.syn[base + lane];                                 \
-                acc[x.x] = acc[x.x] + __uint_as_float(x.y);                         \
-            }                                                                       \
-        }                                                                           \
     __builtin_amdgcn_wave_barrier();
-                LSM_RMW(0)
-                if (n8 > 1) { LSM_RMW(1)
-                if (n8 > 2) { LSM_RMW(2)
-                if (n8 > 3) { LSM_RMW(3)
-                if (n8 > 4) { LSM_RMW(4)
-                if (n8 > 5) { LSM_RMW(5)
-                if (n8 > 6) { LSM_RMW(6)
-                if (n8 > 7) { LSM_RMW(7) } } } } } } }
+#define LSM_RMW_LONG(k)                                                             \
+    if (gb[k] + lane < ge[k]) acc[ent[k].x] = acc[ent[k].x] + __uint_as_float(ent[k].y); \
+    for (uint32_t base = gb[k] + 64u; base < ge[k]; base += 64u) {                  \
+        __builtin_amdgcn_wave_barrier();                                            \
+        if (base + lane < ge[k]) {                                                  \
+            const uint2 x = a.syn[base + lane];                                     \
+            acc[x.x] = acc[x.x] + __uint_as_float(x.y);                             \
+        }                                                                           \
+    }                                                                               \
+    __builtin_amdgcn_wave_barrier();
+                if (!any_long) {                  // common case: every segment fits one instruction
+                    LSM_RMW(0)
+                    if (n8 > 1) { LSM_RMW(1)
+                    if (n8 > 2) { LSM_RMW(2)
+                    if (n8 > 3) { LSM_RMW(3)
+                    if (n8 > 4) { LSM_RMW(4)
+                    if (n8 > 5) { LSM_RMW(5)
+                    if (n8 > 6) { LSM_RMW(6)
+                    if (n8 > 7) { LSM_RMW(7) } } } } } } }
+                } else {
+                    LSM_RMW_LONG(0)
+                    if (n8 > 1) { LSM_RMW_LONG(1)
+                    if (n8 > 2) { LSM_RMW_LONG(2)
+                    if (n8 > 3) { LSM_RMW_LONG(3)
+                    if (n8 > 4) { LSM_RMW_LONG(4)
+                    if (n8 > 5) { LSM_RMW_LONG(5)
+                    if (n8 > 6) { LSM_RMW_LONG(6)
+                    if (n8 > 7) { LSM_RMW_LONG(7) } } } } } } }
+                }
 #undef LSM_RMW
+#undef LSM_RMW_LONG
                 STAMP(3);
             }
         }
@@ -303,24 +338,12 @@ __global__ __launch_bounds__(WPC * 64) void lif_kernel(const LifArgs a)
         }
         unsigned long long bal[SL];
         unsigned long long any_fire = 0ull;
-        uint32_t many = 0u;
 #pragma unroll
         for (int r = 0; r < SL; ++r) {
             const int i = (w * SL + r) * 64 + lane;
             acc[i] = 0.0f;
             icnt[i] = 0u;
-#pragma unroll
-            for (int kq = 0; kq < IN_UNROLL; ++kq) {
-                const float plus = cin[r] + w_in;
-                cin[r] = ((uint32_t)kq < nin[r]) ? plus : cin[r];
-            }
-            many |= (nin[r] > (uint32_t)IN_UNROLL) ? 1u : 0u;
-        }
-        if (__any(many != 0u)) {                 // rare: a neuron with more than IN_UNROLL input hits
-#pragma unroll
-            for (int r = 0; r < SL; ++r)
-                for (uint32_t kq = IN_UNROLL; __any(kq < nin[r]); ++kq)
-                    if (kq < nin[r]) cin[r] = cin[r] + w_in;
+            cin[r] = cin[r] + w_in * (float)nin[r];      // SPEC.md §3: input term after the recurrent sum
         }
 #pragma unroll
         for (int r = 0; r < SL; ++r) {

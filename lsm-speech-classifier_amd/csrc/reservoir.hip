@@ -38,6 +38,7 @@ namespace {
 struct Variant {            // per waves-per-clip layout
     int wpc = 0, sl = 0, einw = 0;
     uint32_t *seg = nullptr;
+    uint16_t *segoff = nullptr;
     float *leak = nullptr;
     int *oslot = nullptr;
     uint32_t *in_ent = nullptr;
@@ -51,6 +52,7 @@ struct lsm_reservoir {
     int device = 0;
     size_t nnz = 0;
     uint2 *syn = nullptr;
+    uint32_t *rowptr = nullptr;
     Variant var[5];         // wpc = 1, 2, 4, 8, 16 (wpc == 0: not available)
 };
 
@@ -58,8 +60,10 @@ static int free_reservoir(lsm_reservoir *h)
 {
     if (!h) return LSM_OK;
     if (h->syn) (void)hipFree(h->syn);
+    if (h->rowptr) (void)hipFree(h->rowptr);
     for (auto &v : h->var) {
         if (v.seg) (void)hipFree(v.seg);
+        if (v.segoff) (void)hipFree(v.segoff);
         if (v.leak) (void)hipFree(v.leak);
         if (v.oslot) (void)hipFree(v.oslot);
         if (v.in_ent) (void)hipFree(v.in_ent);
@@ -122,6 +126,8 @@ int lsm_reservoir_create(lsm_reservoir **out, int num_neurons, int n_channels,
     }
     int rc = upload(&h->syn, syn);
     if (rc) { free_reservoir(h); return rc; }
+    std::vector<uint32_t> rowptr(csc_ptr, csc_ptr + N + 1);
+    if ((rc = upload(&h->rowptr, rowptr))) { free_reservoir(h); return rc; }
 
     const int wpcs[5] = {1, 2, 4, 8, 16};
     for (int vi = 0; vi < 5; ++vi) {
@@ -144,6 +150,13 @@ int lsm_reservoir_create(lsm_reservoir **out, int num_neurons, int n_channels,
             }
         }
         seg[(size_t)N * wpc] = (uint32_t)nnz;
+        // packed form for LDS: u16 offsets relative to the row start, WPC + 1 per neuron
+        std::vector<uint16_t> segoff((size_t)N * (wpc + 1) + 2, 0);
+        for (int j = 0; j < N; ++j) {
+            for (int w = 0; w < wpc; ++w)
+                segoff[(size_t)j * (wpc + 1) + w] = (uint16_t)(seg[(size_t)j * wpc + w] - (uint32_t)csc_ptr[j]);
+            segoff[(size_t)j * (wpc + 1) + wpc] = (uint16_t)(csc_ptr[j + 1] - csc_ptr[j]);
+        }
         std::vector<float> lk(npad, 0.0f);
         std::vector<int> os(npad, -1);
         for (int i = 0; i < N; ++i) lk[i] = leak[i];
@@ -160,7 +173,7 @@ int lsm_reservoir_create(lsm_reservoir **out, int num_neurons, int n_channels,
         std::vector<uint32_t> ent((size_t)wpc * einw, 0xFFFFFFFFu);
         for (int w = 0; w < wpc; ++w)
             std::copy(per[w].begin(), per[w].end(), ent.begin() + (size_t)w * einw);
-        if ((rc = upload(&v.seg, seg)) || (rc = upload(&v.leak, lk)) || (rc = upload(&v.oslot, os)) ||
+        if ((rc = upload(&v.seg, seg)) || (rc = upload(&v.segoff, segoff)) || (rc = upload(&v.leak, lk)) || (rc = upload(&v.oslot, os)) ||
             (rc = upload(&v.in_ent, ent))) {
             free_reservoir(h);
             return rc;
@@ -185,7 +198,8 @@ static size_t lif_lds_core(const lsm_reservoir *h, const Variant &v, int T)
 
 static size_t lif_seg_bytes(const lsm_reservoir *h, const Variant &v)
 {
-    return ((size_t)h->N * v.wpc + 1) * 4;
+    // packed LDS form: (N+1) u32 row pointers + N*(WPC+1) u16 offsets (rounded up to a whole dword)
+    return ((size_t)h->N + 1) * 4 + (((size_t)h->N * (v.wpc + 1) + 1) / 2) * 4;
 }
 
 // The segment table rides in LDS when that still leaves room for >= 2 workgroups per CU's 160 KB.
@@ -244,6 +258,7 @@ int lsm_reservoir_run(const lsm_reservoir *h, const uint8_t *spikes_u8, int n_cl
     a.n_out = h->n_out; a.CW = (h->C + 31) / 32; a.EinW = v->einw;
     a.refractory = h->refractory; a.burst_isi_max = h->burst_isi_max;
     a.theta = h->theta; a.w_in = h->w_in;
+    a.rowptr = h->rowptr; a.segoff = v->segoff;
     a.raster = spikes_u8; a.seg = v->seg; a.syn = h->syn; a.leak = v->leak; a.oslot = v->oslot;
     a.in_ent = v->in_ent;
     a.n_keys = n_keys;

@@ -193,7 +193,7 @@ ORC_API void orc_encode_hysteresis_f32(const float *spec, int n_filters, int n_b
 
 /* ---------------------------------------------------------------------------------------------
  * LIF reservoir, SPEC.md §3 (gather form, literal) + §4 features.  float32 throughout, one
- * accumulator per neuron: presynaptic j ascending, then input channels ascending.
+ * accumulator per neuron: presynaptic j ascending, then w_in * (active input count).
  * key ids: 0 spike_counts, 1 spike_variances, 2 mean_spike_times, 3 first_spike_times,
  *          4 last_spike_times, 5 mean_isi, 6 isi_variances, 7 burst_counts.
  * features: (n_keys, n_out) float32 with NaN already replaced by 0 (extract_lsm_features.py:85).
@@ -224,13 +224,15 @@ ORC_API int orc_lif_run(int N, int C, int T,
 
     for (int t = 0; t < T; ++t) {
         for (int i = 0; i < N; ++i) {
-            /* SPEC.md §3: one float32 accumulator; presynaptic neurons ascending first, then
-             * input channels ascending */
+            /* SPEC.md §3: one float32 accumulator over the presynaptic neurons, ascending; then the
+             * input term w_in * (number of active input channels of neuron i at step t) */
             float cur = 0.0f;
             for (int e = csr_ptr[i]; e < csr_ptr[i + 1]; ++e)
                 cur += csr_w[e] * (float)s_prev[csr_pre[e]];
+            int m_in = 0;
             for (int e = in_ptr[i]; e < in_ptr[i + 1]; ++e)
-                cur += w_in * (float)(raster[(size_t)in_chan[e] * T + t] != 0);   /* any non-zero byte is a spike */
+                m_in += raster[(size_t)in_chan[e] * T + t] != 0;              /* any non-zero byte is a spike */
+            cur += w_in * (float)m_in;
             int fire = 0;
             if (ref[i] > 0) {
                 ref[i] -= 1;
