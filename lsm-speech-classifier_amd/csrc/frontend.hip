@@ -79,15 +79,22 @@ __global__ __launch_bounds__(64) void gammatone_kernel(
         }
         return o * o;
     };
-    // samples [n, n_to) with the NACT youngest windows accumulating
+    // samples [n, n_to) with the NACT youngest windows accumulating; the scalar load of the next
+    // 8 samples is issued before the current 8 are consumed (clamped inside the clip: the extra chunk
+    // at the end of a run is loaded but never used)
 #define LSM_RUN(n_to, NACT)                                                         \
     {                                                                               \
-        for (; n + 8 <= (n_to); n += 8) {                                           \
-            float xs[8];                                                            \
+        if (n + 8 <= (n_to)) {                                                      \
+            float xs[8], nx[8];                                                     \
             _Pragma("unroll") for (int u = 0; u < 8; ++u) xs[u] = x[n + u];         \
-            _Pragma("unroll") for (int u = 0; u < 8; ++u) {                         \
-                const double e = filt(xs[u]);                                       \
-                _Pragma("unroll") for (int q = 0; q < (NACT); ++q) win[q] += e;     \
+            for (; n + 8 <= (n_to); n += 8) {                                       \
+                const float *pn = x + min(n + 8, n_samples - 8);                    \
+                _Pragma("unroll") for (int u = 0; u < 8; ++u) nx[u] = pn[u];        \
+                _Pragma("unroll") for (int u = 0; u < 8; ++u) {                     \
+                    const double e = filt(xs[u]);                                   \
+                    _Pragma("unroll") for (int q = 0; q < (NACT); ++q) win[q] += e; \
+                }                                                                   \
+                _Pragma("unroll") for (int u = 0; u < 8; ++u) xs[u] = nx[u];        \
             }                                                                       \
         }                                                                           \
         for (; n < (n_to); ++n) {                                                   \
@@ -343,6 +350,7 @@ LSM_API int lsm_gammatone_spec_f64(const float *audio, int n_clips, int n_sample
     LSM_REQUIRE(nwin <= NWIN_MAX * hop, "nwin=%d needs more than %d overlapping windows of hop=%d",
                 nwin, NWIN_MAX, hop);
     LSM_REQUIRE((long)(ncols - 1) * hop + nwin <= n_samples, "columns exceed the clip");
+    LSM_REQUIRE(n_samples >= 8, "clips shorter than 8 samples are not supported");
     LSM_REQUIRE(n_clips <= 65535, "at most 65535 clips per call (grid.y)");
     const dim3 grid((unsigned)((n_filters + 63) / 64), (unsigned)n_clips);
     const bool fast = (coef_flags & 3) == 3;       // both properties verified by the host
