@@ -105,8 +105,8 @@ def cpu_baseline(cfg, audio, res, seconds_budget=20.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--config", default="cfg2", choices=sorted(CONFIGS))
     ap.add_argument("--batch", type=int, default=0, help="clips per GPU (0 = the config's)")
     ap.add_argument("--waves-per-clip", type=int, default=0)
@@ -122,15 +122,19 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world > 1:
+    # LSM_BENCH_FORCE_DIST=1 takes the distributed code path (process group, broadcast, gather,
+    # barrier) even with one rank: a rehearsal of the RCCL calls on a 1-GPU box
+    use_dist = world > 1 or os.environ.get("LSM_BENCH_FORCE_DIST") == "1"
+    if use_dist:
         import torch.distributed as dist
+        os.environ.setdefault("MASTER_PORT", "29531")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local_rank)
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     else:
         torch.cuda.set_device(0)
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
-    dev = torch.device("cuda", local_rank if world > 1 else 0)
+    dev = torch.device("cuda", local_rank if use_dist else 0)
 
     from lsm_speech_classifier_amd import frontend, reservoir, snn
     cfg = CONFIGS[args.config]
@@ -142,7 +146,7 @@ def main():
     # one-off setup exactly like extract_lsm_features.main: rasters -> w_critico -> reservoir
     rasters0 = fe.encode(audio)
     wc = w_critico(cfg["k"], 2.0, 2, rasters0)
-    if world > 1:                                  # every rank must build the SAME reservoir
+    if use_dist:                                  # every rank must build the SAME reservoir
         t = torch.tensor([wc], dtype=torch.float64, device=dev)
         dist.broadcast(t, 0)
         wc = float(t.item())
@@ -151,13 +155,15 @@ def main():
     res = reservoir.build_reservoir(params, fe.n_channels)
     net = snn.SNN(params, reservoir=res, device=dev)
     n_feat = len(FEATURE_SET) * cfg["n_out"]
-    gathered = torch.empty((world * B, n_feat), dtype=torch.float32, device=dev) if world > 1 else None
     lay = net.layout(B, fe.n_steps, args.waves_per_clip)
 
     ev_pairs = []
     n_streams = max(1, args.streams)
     streams = [torch.cuda.Stream(device=dev) for _ in range(n_streams)] if n_streams > 1 else [None]
     step_no = [0]
+    # one gather buffer per stream of the rotation: overlapping steps never share an output
+    gather_bufs = ([torch.empty((world * B, n_feat), dtype=torch.float32, device=dev)
+                    for _ in range(n_streams)] if use_dist else None)
 
     split = args.pipeline == "split" and args.stage == "full" and n_streams > 1
 
@@ -191,7 +197,9 @@ def main():
             if timed:
                 e1.record()
                 ev_pairs.append((e0, e1))
-            if world > 1:
+            if use_dist:
+                step_no[0] += 1
+                gathered = gather_bufs[step_no[0] % n_streams]
                 dist.all_gather_into_tensor(gathered, feats)
                 return gathered
             return feats
@@ -210,14 +218,15 @@ def main():
         if timed:
             e1.record()
             ev_pairs.append((e0, e1))
-        if world > 1:
+        if use_dist:
+            gathered = gather_bufs[(step_no[0] - 1) % n_streams]
             dist.all_gather_into_tensor(gathered, feats)
             return gathered
         return feats
 
     def fence():
         torch.cuda.synchronize()
-        if world > 1:
+        if use_dist:
             dist.barrier()
             torch.cuda.synchronize()
 
@@ -232,7 +241,7 @@ def main():
         out = step(True)
     fence()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -304,7 +313,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(cfg, audio_np, res)
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 
