@@ -322,7 +322,8 @@ template <typename T>
 int launch_encode(const T *spec, int n_rows, int n_bins, const T *thr_on, const T *thr_off,
                   int n_thr, uint8_t *out, void *stream)
 {
-    LSM_REQUIRE(n_rows >= 0 && n_bins >= 1 && n_thr >= 1 && n_thr <= MAX_THR, "bad shape");
+    LSM_REQUIRE(n_rows >= 0 && n_bins >= 1, "encode: bad shape (%d rows, %d bins)", n_rows, n_bins);
+    LSM_REQUIRE(n_thr >= 1 && n_thr <= MAX_THR, "n_thr=%d outside [1, %d]", n_thr, MAX_THR);
     if (n_rows == 0) return LSM_OK;
     LSM_REQUIRE(spec && out && thr_on && thr_off, "encode: null buffer");
     SpikeArgs<T> a{};

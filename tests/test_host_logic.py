@@ -211,3 +211,19 @@ def test_load_audio_file_and_readout(tmp_path, monkeypatch, capsys):
     acc = tc.train_and_evaluate_classifier()
     assert acc > 0.9
     capsys.readouterr()
+
+
+def test_train_classifier_torch_readouts(tmp_path, monkeypatch, capsys):
+    import train_classifier as tc
+    rs = np.random.RandomState(1)
+    monkeypatch.chdir(tmp_path)
+    y = np.repeat(np.arange(4), 30).astype(np.int32)
+    X = rs.randn(120, 12) + y[:, None] * 2.5
+    np.savez_compressed("lsm_features_larger.npz", X_train_features=X[::2], y_train=y[::2],
+                        X_test_features=X[1::2], y_test=y[1::2], feature_set="original",
+                        leak_variance_divisor=None)
+    base = tc.train_and_evaluate_classifier()
+    for kind in ("torch-logistic", "torch-ridge"):
+        acc = tc.train_and_evaluate_classifier(readout=kind)
+        assert acc > 0.9 and abs(acc - base) <= 0.1
+    capsys.readouterr()

@@ -25,8 +25,28 @@ def _readout():
     return LogisticRegression(**kw)
 
 
-def train_and_evaluate_classifier():
+class _TorchReadout:
+    """Adapter giving the PyTorch readouts scikit-learn's fit/predict on NumPy arrays."""
+
+    def __init__(self, kind: str):
+        import torch
+        from lsm_speech_classifier_amd import readout
+        self.torch = torch
+        self.dev = "cuda" if torch.cuda.is_available() else "cpu"
+        self.model = readout.RidgeReadout(1.0) if kind == "torch-ridge" else readout.LogisticReadout(1.0, 1000)
+
+    def fit(self, X, y):
+        t = self.torch
+        self.model.fit(t.from_numpy(np.asarray(X)).to(self.dev), t.from_numpy(np.asarray(y)).to(self.dev))
+        return self
+
+    def predict(self, X):
+        return self.model.predict(self.torch.from_numpy(np.asarray(X)).to(self.dev)).cpu().numpy()
+
+
+def train_and_evaluate_classifier(readout=None):
     from sklearn.metrics import accuracy_score, classification_report
+    readout = readout or os.environ.get("LSM_READOUT", "sklearn")
     if not Path(FEATURE_FILE).exists():
         print("Error: Dataset file not found. Please run 'extract_lsm_features.py' first.")
         return
@@ -35,8 +55,9 @@ def train_and_evaluate_classifier():
         X_test, y_test = data['X_test_features'], data['y_test']
     print(f"Loaded {len(X_train)} training and {len(X_test)} test samples.")
 
-    print("Training the Logistic Regression classifier...")
-    clf = _readout()
+    print("Training the Logistic Regression classifier..." if readout != "torch-ridge"
+          else "Training the ridge classifier...")
+    clf = _readout() if readout == "sklearn" else _TorchReadout(readout)
     clf.fit(X_train, y_train)
     print("Training complete.")
 
