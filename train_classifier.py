@@ -1,9 +1,12 @@
 """Stage 3 of the pipeline: LSM features (File 2) -> linear readout, accuracy and report.
 
-Drop-in for the reference script of the same name (/root/reference/train_classifier.py): the
-readout stays a host-side multinomial logistic regression, as BASELINE.json's north_star asks.
+Drop-in for the reference script of the same name (/root/reference/train_classifier.py): by default
+the readout is scikit-learn's multinomial logistic regression on the host, exactly as there.
+``LSM_READOUT=torch-logistic`` or ``torch-ridge`` (or the ``readout=`` argument) runs the PyTorch
+readouts of ``lsm_speech_classifier_amd.readout`` on the GPU instead.
 """
 import inspect
+import os
 from pathlib import Path
 
 import numpy as np
