@@ -218,7 +218,7 @@ def test_train_classifier_torch_readouts(tmp_path, monkeypatch, capsys):
     rs = np.random.RandomState(1)
     monkeypatch.chdir(tmp_path)
     y = np.repeat(np.arange(4), 30).astype(np.int32)
-    X = rs.randn(120, 12) + y[:, None] * 2.5
+    X = rs.randn(120, 12) + (rs.randn(4, 12) * 3.0)[y]      # class means in general position
     np.savez_compressed("lsm_features_larger.npz", X_train_features=X[::2], y_train=y[::2],
                         X_test_features=X[1::2], y_test=y[1::2], feature_set="original",
                         leak_variance_divisor=None)
