@@ -247,6 +247,10 @@ int lsm_reservoir_run(const lsm_reservoir *h, const uint8_t *spikes_u8, int n_cl
     LSM_REQUIRE(n_keys >= 1 && n_keys <= 8 && key_ids, "n_keys must be in [1, 8]");
     if (n_clips == 0) return LSM_OK;            // empty batch: nothing to read or write
     LSM_REQUIRE(spikes_u8 && features_out, "null buffer");
+    int dev_now = -1;
+    LSM_CHECK_HIP(hipGetDevice(&dev_now));
+    LSM_REQUIRE(dev_now == h->device, "reservoir handle lives on device %d but the current device is %d",
+                h->device, dev_now);
     const Variant *v = choose_variant(h, n_clips, n_steps, waves_per_clip);
     LSM_REQUIRE(v != nullptr, "no reservoir layout for waves_per_clip=%d (N=%d, T=%d)",
                 waves_per_clip, h->N, n_steps);

@@ -1,8 +1,12 @@
 """Run the three pipeline stages in order, each as its own Python process (like the reference's
 main.py, which shells out and ignores exit codes: /root/reference/main.py:19-27)."""
 import argparse
+import os
 import subprocess
 import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))     # the stage scripts live next to this file;
+                                                      # data files stay relative to the working directory
 
 STAGES = (
     ("Step 1: Creating Spike Train Dataset",
@@ -21,7 +25,8 @@ def run_pipeline(n_filters: int, filterbank: str, feature_set: str, multiplier: 
     print("--- Running Pipeline ---")
     for title, command in STAGES:
         print(f"\n--- {title} ---", flush=True)
-        subprocess.call([sys.executable] + command(args))
+        cmd = command(args)
+        subprocess.call([sys.executable, os.path.join(HERE, cmd[0])] + cmd[1:])
     print("\n--- Pipeline Finished ---")
 
 
