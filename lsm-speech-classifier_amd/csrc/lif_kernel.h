@@ -268,7 +268,7 @@ __global__ __launch_bounds__(WPC * 64) void lif_kernel(const LifArgs a)
         todo &= todo - 1ull;                                                        \
         gb[k] = __builtin_amdgcn_readlane(beg, sk);                                 \
         ge[k] = __builtin_amdgcn_readlane(end, sk);                                 \
-        any_long |= (ge[k] - gb[k]) > 64u;                                          \
+        if (SL > 1) any_long |= (ge[k] - gb[k]) > 64u;   /* SL == 1: a wave owns 64 targets */ \
         if (gb[k] + lane < ge[k]) ent[k] = a.syn[gb[k] + lane];                     \
     }
                 LSM_LD(0)
@@ -300,7 +300,7 @@ __global__ __launch_bounds__(WPC * 64) void lif_kernel(const LifArgs a)
         }                                                                           \
     }                                                                               \
     __builtin_amdgcn_wave_barrier();
-                if (!any_long) {                  // common case: every segment fits one instruction
+                if (SL == 1 || !any_long) {       // common case: every segment fits one instruction
                     LSM_RMW(0)
                     if (n8 > 1) { LSM_RMW(1)
                     if (n8 > 2) { LSM_RMW(2)
