@@ -1,0 +1,46 @@
+"""bench.py's driver contract on the GPU box: one JSON line with the required keys, the roofline and
+cpu_baseline objects, and sane values (tiny K so the test stays short)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run(*extra):
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "6", "--warmup", "2", *extra],
+                         capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout
+    return json.loads(lines[0])
+
+
+def test_bench_line_contract():
+    d = _run("--batch", "64")
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better",
+                "scaling", "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert key in d, key
+    assert d["unit"] == "clips/s" and d["n_gpus"] == 1 and d["steps"] == 6 and d["warmup"] == 2
+    assert d["higher_is_better"] is True and d["scaling"] == "weak" and d["vs_baseline"] is None
+    assert d["data"] == "synthetic" and "workload" in d["config"] and "model" not in d["config"]
+    assert d["value"] > 0 and abs(d["value"] - 64 / (d["ms_per_step"] * 1e-3)) / d["value"] < 1e-3
+    r = d["roofline"]
+    for key in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert key in r, key
+    assert r["bound"] == "hbm" and r["peak"] == 8000.0 and r["unit"] == "GB/s"
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-4 and r["kernel_ms"] > 0
+    c = d["cpu_baseline"]
+    assert c["kind"] == "port" and c["cores"] == 1 and c["unit"] == "clips/s" and c["value"] > 0 and c["sample"]
+    assert d["value"] / c["value"] > 100           # north star: >= 100x the CPU reference at 1 GPU
+
+
+def test_bench_stages_and_serial_mode():
+    d = _run("--batch", "64", "--stage", "reservoir", "--no-cpu-baseline", "--streams", "1")
+    assert "cpu_baseline" not in d and d["config"]["stage"] == "reservoir" and d["config"]["pipeline"] == "serial"
+    d = _run("--batch", "64", "--stage", "frontend", "--no-cpu-baseline")
+    assert "roofline" not in d and d["value"] > 0
