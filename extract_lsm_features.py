@@ -101,6 +101,13 @@ def run_network_diagnostics(lsm, X_sample_batch):
     print("\n" + "=" * 40 + "\nRUNNING NETWORK DIAGNOSTICS\n" + "=" * 40)
     n_neurons = lsm.num_neurons
     participation = []
+    if hasattr(lsm, "diagnostics"):                      # one batched launch, statistics on the device
+        d = lsm.diagnostics(np.ascontiguousarray(X_sample_batch[:5]))
+        for i in range(len(d["participation"])):
+            participation.append(float(d["participation"][i]))
+            print(f"Sample {i + 1}: Active: {participation[-1]:.1f}% | Dead: {int(d['dead_neurons'][i])} | "
+                  f"Avg Spikes/Neuron: {float(d['mean_spikes_per_neuron'][i]):.2f}")
+        X_sample_batch = X_sample_batch[:0]
     for i, sample in enumerate(X_sample_batch[:5]):
         lsm.reset()
         lsm.set_input_spike_times(sample)

@@ -100,6 +100,19 @@ class SNN:
                 "lsm_reservoir_run")
         return feats, sm, vt
 
+    def diagnostics(self, spikes) -> dict:
+        """Batched health statistics (the quantities /root/reference/extract_lsm_features.py:119-133
+        derives per clip from ``lsm.spike_matrix``), reduced on the device: per clip the share of
+        neurons that fired at least once, the number of silent neurons and the mean spikes per neuron."""
+        _, sm, _ = self.run_batch(spikes, ['spike_counts'], want_spike_matrix=True)
+        per_neuron = sm.sum(dim=1, dtype=torch.int32)                    # (B, N)
+        active = (per_neuron > 0).sum(dim=1)
+        return {
+            "participation": (active.double() / self.num_neurons * 100).cpu().numpy(),
+            "dead_neurons": (self.num_neurons - active).cpu().numpy(),
+            "mean_spikes_per_neuron": per_neuron.double().mean(dim=1).cpu().numpy(),
+        }
+
     def layout(self, n_clips: int, n_steps: int, waves_per_clip: int = 0):
         wpc, sl, lds = C.c_int(), C.c_int(), C.c_int()
         _lib.check(self.lib.lsm_reservoir_layout(self._handle, n_clips, n_steps, waves_per_clip,

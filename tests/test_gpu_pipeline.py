@@ -80,3 +80,21 @@ def test_diagnostics_band_on_speech_like_input():
     p.weight_variance = 10
     avg = ex.run_network_diagnostics(SNN(simulation_params=p), rasters)
     assert 40.0 <= avg <= 98.0
+
+
+def test_batched_diagnostics_equal_the_per_clip_protocol():
+    """SNN.diagnostics (one launch, device reductions) vs the reference's per-clip recipe on
+    lsm.spike_matrix (extract_lsm_features.py:113-133)."""
+    from lsm_speech_classifier_amd import synth
+    from lsm_speech_classifier_amd.snn import SNN, SimulationParams
+    rasters = synth.bernoulli_raster(5, 32, 200, 0.15, seed=4)
+    p = SimulationParams(num_neurons=300, num_output_neurons=100, small_world_graph_k=30, mean_weight=0.04,
+                         input_spike_times=rasters[0])
+    net = SNN(simulation_params=p)
+    d = net.diagnostics(rasters)
+    for i, r in enumerate(rasters):
+        net.reset(); net.set_input_spike_times(r); net.simulate()
+        per = net.spike_matrix.sum(axis=0)
+        assert d["participation"][i] == np.count_nonzero(per) / 300 * 100
+        assert d["dead_neurons"][i] == 300 - np.count_nonzero(per)
+        assert d["mean_spikes_per_neuron"][i] == per.mean()
