@@ -106,11 +106,12 @@ class SNN:
         neurons that fired at least once, the number of silent neurons and the mean spikes per neuron."""
         _, sm, _ = self.run_batch(spikes, ['spike_counts'], want_spike_matrix=True)
         per_neuron = sm.sum(dim=1, dtype=torch.int32)                    # (B, N)
-        active = (per_neuron > 0).sum(dim=1)
+        active = (per_neuron > 0).sum(dim=1).cpu().numpy()                # exact integers from here on
+        total = per_neuron.sum(dim=1, dtype=torch.int64).cpu().numpy()
         return {
-            "participation": (active.double() / self.num_neurons * 100).cpu().numpy(),
-            "dead_neurons": (self.num_neurons - active).cpu().numpy(),
-            "mean_spikes_per_neuron": per_neuron.double().mean(dim=1).cpu().numpy(),
+            "participation": active / self.num_neurons * 100,           # same expression as the reference
+            "dead_neurons": self.num_neurons - active,
+            "mean_spikes_per_neuron": total / self.num_neurons,
         }
 
     def layout(self, n_clips: int, n_steps: int, waves_per_clip: int = 0):
