@@ -107,6 +107,11 @@ int lsm_reservoir_create(lsm_reservoir **out, int num_neurons, int n_channels,
                          int burst_isi_max);
 int lsm_reservoir_destroy(lsm_reservoir *h);
 
+/* Kernel used by lsm_reservoir_run for this handle: 0 = choose (dense presynaptic rows with register
+ * accumulation for reservoirs of <= 2048 neurons, else the sparse CSC scatter), 1 = sparse, 2 = dense.
+ * Both produce bit-identical results (SPEC.md §3). */
+int lsm_reservoir_set_kernel(lsm_reservoir *h, int mode);
+
 /* Replaces, for a whole batch, the per-clip loop body of extract_all_features
  * (extract_lsm_features.py:78-87): reset -> set_input_spike_times -> simulate ->
  * extract_features_from_spikes -> nan_to_num -> concatenate in key order.

@@ -1,0 +1,375 @@
+// lif_dense.h -- LIF reservoir time loop for SMALL reservoirs (dense presynaptic rows), gfx950.
+//
+// Same contract as lif_kernel.h (SPEC.md §3-§4; replaces reset/set_input_spike_times/simulate/
+// extract_features_from_spikes of /root/reference/extract_lsm_features.py:79-83), different data
+// structure: W is stored as dense rows by PRESYNAPTIC neuron, Wt[j][i] (0 where there is no synapse),
+// N x LD floats = 4 MB at N = 1000, which lives in L2 / Infinity Cache.  For every neuron j that spiked
+// at t-1, ascending, each lane loads the weight onto ITS OWN target neuron (one coalesced 256-byte load
+// per wave and 64-neuron slot) and adds it to a REGISTER accumulator.  The oracle's per-target sum runs
+// over the existing synapses in ascending j; the extra terms here are exact zeros and x + 0 = x in
+// float32, so the result is bit-identical.  What this removes compared with the sparse kernel: the LDS
+// current accumulators and their ordered read-modify-write chain (a burst of n spikes cost n dependent LDS
+// round trips on the few waves owning the targets), the segment tables, the exec masking -- every wave does
+// the same S loads + S adds, so bursts no longer unbalance the waves.  What it costs: N*4 bytes per spiking
+// neuron and clip from L2/MALL instead of ~8 bytes per synapse (4 KB vs 1.6 KB at N = 1000).
+//
+// Spike exchange: each producer wave writes its spiking neurons (ballot + mbcnt ranks, ascending) into its
+// own LDS list; the first R = 64/WPC also go to the wave's fixed region of a 64-entry step list, so lane l of
+// a consumer knows its entry (l) and whether it is filled (l%R < count of producer l/R) without any merge;
+// a producer with more than R spikes raises a (triple-buffered) overflow word and the consumers merge the
+// per-wave lists for that step (scalar prefix over the counts + compare chain).
+#pragma once
+#include "lif_kernel.h"
+
+namespace lsm_lif {
+
+struct DenseArgs {
+    int N, C, T, B;
+    int n_out, CW, EinW, refractory, burst_isi_max, ld;
+    float theta, w_in;
+    const uint8_t *raster;     // (B, C, T) uint8
+    const float *wt;           // (N, ld) dense rows by presynaptic neuron
+    const float *leak;         // (NPAD)
+    const int *oslot;          // (NPAD) output slot or -1
+    const uint32_t *in_ent;    // (WPC, EinW) (channel << 16) | target, 0xFFFFFFFF = padding
+    int n_keys;
+    int key_ids[8];
+    float *features;           // (B, n_keys * n_out)
+    uint8_t *spike_matrix;     // (B, T, N) or null
+    float *v_trace;            // (B, T, N) or null
+};
+
+template <int SL, int WPC, bool INREG>
+__global__ __launch_bounds__(WPC * 64) void lif_dense_kernel(const DenseArgs a)
+{
+    constexpr int NPW = SL * 64;
+    constexpr int NPAD = NPW * WPC;
+    constexpr int NT = WPC * 64;
+    constexpr int R = 64 / WPC;            // fixed-region list entries per producer wave
+    constexpr int G = 16 / SL;             // rows in flight per group (G*SL = 16 registers)
+
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    uint32_t *icnt = reinterpret_cast<uint32_t *>(smem);                              // NPAD
+    uint16_t *wlist = reinterpret_cast<uint16_t *>(icnt + NPAD);                      // 2*NPAD
+    uint32_t *wcnt = reinterpret_cast<uint32_t *>(wlist + 2 * NPAD);                  // 2*16 counts, 3 overflow words
+    uint16_t *flist = reinterpret_cast<uint16_t *>(wcnt + 64);                        // 2*64 fixed-region list
+    uint4 *feat = reinterpret_cast<uint4 *>(wcnt + 128);                              // n_out
+    uint32_t *bits = reinterpret_cast<uint32_t *>(feat + a.n_out);                    // T*CW
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int b = blockIdx.x;
+    const int N = a.N, T = a.T, CW = a.CW;
+
+    // ---- prologue: zero LDS state, bit-pack the clip's raster time-major ----
+    for (int i = tid; i < NPAD; i += NT) icnt[i] = 0u;
+    if (tid < 64) wcnt[tid] = 0u;
+    for (int i = tid; i < a.n_out; i += NT) feat[i] = make_uint4(0, 0, 0, 0);
+    for (int i = tid; i < T * CW; i += NT) bits[i] = 0u;
+    __syncthreads();
+    {
+        const uint8_t *clip = a.raster + (size_t)b * a.C * T;
+        if ((T & 3) == 0) {
+            const uint32_t *clip4 = reinterpret_cast<const uint32_t *>(clip);
+            const int nd = a.C * T / 4;
+            for (int q = tid; q < nd; q += NT) {
+                const uint32_t v = clip4[q];
+                if (v == 0) continue;
+                const int c = (q * 4) / T;
+                const int t0 = (q * 4) - c * T;
+                const uint32_t bit = 1u << (c & 31);
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    if ((v >> (8 * k)) & 0xFFu) atomicOr(&bits[(t0 + k) * CW + (c >> 5)], bit);
+            }
+        } else {
+            const int nb = a.C * T;
+            for (int q = tid; q < nb; q += NT)
+                if (clip[q]) {
+                    const int c = q / T;
+                    atomicOr(&bits[(q - c * T) * CW + (c >> 5)], 1u << (c & 31));
+                }
+        }
+    }
+
+    float v[SL], lam[SL];
+    int ref[SL], os[SL];
+#pragma unroll
+    for (int r = 0; r < SL; ++r) {
+        const int i = (w * SL + r) * 64 + lane;
+        v[r] = 0.0f;
+        ref[r] = 0;
+        lam[r] = a.leak[i];
+        os[r] = a.oslot[i];
+    }
+    uint32_t in_word[IN_REG_SLOTS], in_mask[IN_REG_SLOTS], in_tgt[IN_REG_SLOTS];
+    if (INREG) {
+#pragma unroll
+        for (int q = 0; q < IN_REG_SLOTS; ++q) {
+            const int e = q * 64 + lane;
+            const uint32_t x = e < a.EinW ? a.in_ent[(size_t)w * a.EinW + e] : 0xFFFFFFFFu;
+            const bool ok = x != 0xFFFFFFFFu;
+            const uint32_t c = x >> 16;
+            in_word[q] = ok ? (c >> 5) : 0u;
+            in_mask[q] = ok ? (1u << (c & 31)) : 0u;
+            in_tgt[q] = ok ? (x & 0xFFFFu) : (uint32_t)(w * NPW + lane);   // padding: own slot, adds 0
+        }
+    }
+    const float theta = a.theta, w_in = a.w_in;
+    const uint32_t *my_ent = a.in_ent + (size_t)w * a.EinW;
+    const bool trace = a.spike_matrix != nullptr || a.v_trace != nullptr;
+    const float *wt_mine = a.wt + (size_t)(w * NPW) + lane;     // + j*ld + r*64: weight j -> my target
+    const size_t ld = (size_t)a.ld;
+    __syncthreads();
+
+    // input drive of step `ts`: count the active channels feeding each target (integer atomics)
+    auto input_drive = [&](int ts) {
+        const uint32_t *row = bits + ts * CW;
+        if (INREG) {
+#pragma unroll
+            for (int q = 0; q < IN_REG_SLOTS; q += 2) {
+                if (q * 64 < a.EinW) {          // two slots at a time, only as many as the map needs
+                    const uint32_t w0 = row[in_word[q]], w1 = row[in_word[q + 1]];
+                    atomicAdd(icnt + in_tgt[q], (w0 & in_mask[q]) ? 1u : 0u);
+                    if ((q + 1) * 64 < a.EinW) atomicAdd(icnt + in_tgt[q + 1], (w1 & in_mask[q + 1]) ? 1u : 0u);
+                }
+            }
+        } else {
+            for (int e = lane; e < a.EinW; e += 64) {
+                const uint32_t x = my_ent[e];
+                if (x != 0xFFFFFFFFu) {
+                    const uint32_t c = x >> 16;
+                    atomicAdd(icnt + (x & 0xFFFFu), (row[c >> 5] >> (c & 31)) & 1u);
+                }
+            }
+        }
+    };
+
+    for (int t = 0; t < T; ++t) {
+        const int cur = t & 1, prv = cur ^ 1;
+        const uint16_t *list_prev = wlist + prv * NPAD;
+        uint16_t *list_cur = wlist + cur * NPAD + w * NPW;
+        // overflow words are triple-buffered by t mod 3: producers of step t set word t%3, consumers of
+        // step t+1 read it, it is cleared during step t+2 -- three steps, each separated by the barrier
+        const int f_set = t % 3, f_read = (t + 2) % 3, f_clear = (t + 1) % 3;
+
+        float cin[SL];
+#pragma unroll
+        for (int r = 0; r < SL; ++r) cin[r] = 0.0f;
+
+        // `todo`: filled entries of the step list; lane l holds entry l's neuron in `jl`.  Up to 8 rows
+        // (G = 16/SL) are in flight; nested "one more?" tests make a group cost one taken branch.
+        bool drove = false;
+        auto add_rows = [&](unsigned long long todo, uint32_t jl) {
+            while (todo != 0ull) {
+                const int n8 = min((int)__popcll(todo), G);
+                float wv[16][SL];                   // only the first G rows are ever live
+#define LSM_LD(k)                                                                   \
+    {                                                                               \
+        const int sk = __builtin_ctzll(todo);                                       \
+        todo &= todo - 1ull;                                                        \
+        const uint32_t j = __builtin_amdgcn_readlane(jl, sk);                       \
+        const float *rowp = wt_mine + (size_t)j * ld;                               \
+        _Pragma("unroll") for (int r = 0; r < SL; ++r) wv[k][r] = rowp[r * 64];     \
+    }
+                LSM_LD(0)
+                if (n8 > 1) { LSM_LD(1)
+                if (n8 > 2) { LSM_LD(2)
+                if (n8 > 3) { LSM_LD(3)
+                if (n8 > 4) { LSM_LD(4)
+                if (n8 > 5) { LSM_LD(5)
+                if (n8 > 6) { LSM_LD(6)
+                if (n8 > 7) { LSM_LD(7)
+                if (n8 > 8) { LSM_LD(8)
+                if (n8 > 9) { LSM_LD(9)
+                if (n8 > 10) { LSM_LD(10)
+                if (n8 > 11) { LSM_LD(11)
+                if (n8 > 12) { LSM_LD(12)
+                if (n8 > 13) { LSM_LD(13)
+                if (n8 > 14) { LSM_LD(14)
+                if (n8 > 15) { LSM_LD(15) } } } } } } } } } } } } } } }
+#undef LSM_LD
+                if (!drove) {                     // the input counts fill the load latency
+                    input_drive(t);
+                    drove = true;
+                }
+#define LSM_ADD(k) _Pragma("unroll") for (int r = 0; r < SL; ++r) cin[r] = cin[r] + wv[k][r];
+                LSM_ADD(0)
+                if (n8 > 1) { LSM_ADD(1)
+                if (n8 > 2) { LSM_ADD(2)
+                if (n8 > 3) { LSM_ADD(3)
+                if (n8 > 4) { LSM_ADD(4)
+                if (n8 > 5) { LSM_ADD(5)
+                if (n8 > 6) { LSM_ADD(6)
+                if (n8 > 7) { LSM_ADD(7)
+                if (n8 > 8) { LSM_ADD(8)
+                if (n8 > 9) { LSM_ADD(9)
+                if (n8 > 10) { LSM_ADD(10)
+                if (n8 > 11) { LSM_ADD(11)
+                if (n8 > 12) { LSM_ADD(12)
+                if (n8 > 13) { LSM_ADD(13)
+                if (n8 > 14) { LSM_ADD(14)
+                if (n8 > 15) { LSM_ADD(15) } } } } } } } } } } } } } } }
+#undef LSM_ADD
+            }
+        };
+
+        // ---- spiking neurons of step t-1 ----
+        const uint32_t pcnt = wcnt[prv * 16 + lane / R];            // spikes of producer wave lane/R
+        const uint32_t jfix = flist[prv * 64 + lane];               // its (lane%R)-th spiking neuron
+        const uint32_t overflow = wcnt[32 + f_read];
+        if (tid == 0) wcnt[32 + f_clear] = 0u;
+        if (__builtin_amdgcn_readfirstlane(overflow) == 0u) {
+            add_rows(__ballot((uint32_t)(lane % R) < pcnt), jfix);
+        } else {
+            // general path: merge the per-wave lists (scalar prefix over the counts, compare chain)
+            const uint32_t cv = wcnt[prv * 16 + (lane & 15)];
+            uint32_t pre[WPC + 1];
+            pre[0] = 0u;
+#pragma unroll
+            for (int q = 0; q < WPC; ++q) pre[q + 1] = pre[q] + __builtin_amdgcn_readlane(cv, q);
+            const uint32_t total = pre[WPC];
+            for (uint32_t l0 = 0; l0 < total; l0 += 64) {
+                const uint32_t l = l0 + lane;
+                uint32_t wsel = 0u, pbase = 0u;
+#pragma unroll
+                for (int q = 1; q < WPC; ++q) {
+                    const bool ge = l >= pre[q];
+                    wsel += ge ? 1u : 0u;
+                    pbase = ge ? pre[q] : pbase;
+                }
+                uint32_t jl = 0u;
+                if (l < total) jl = list_prev[wsel * NPW + (l - pbase)];
+                add_rows(__ballot(l < total), jl);
+            }
+        }
+        if (!drove) input_drive(t);
+        wave_lds_fence();
+
+        // ---- neuron update ----
+        unsigned long long bal[SL];
+        unsigned long long any_fire = 0ull;
+#pragma unroll
+        for (int r = 0; r < SL; ++r) {
+            const int i = (w * SL + r) * 64 + lane;
+            const uint32_t nin = icnt[i];
+            icnt[i] = 0u;
+            cin[r] = cin[r] + w_in * (float)nin;         // SPEC.md §3: input term after the recurrent sum
+            const bool held = ref[r] > 0;
+            const float m = lam[r] * v[r];
+            const float d = v[r] - m;
+            const float vn = d + cin[r];
+            const bool fire = !held && (vn >= theta);
+            v[r] = (held || fire) ? 0.0f : vn;
+            ref[r] = held ? ref[r] - 1 : (fire ? a.refractory : 0);
+            bal[r] = __ballot(fire);
+            any_fire |= bal[r];
+        }
+        int nspk = 0;
+        if (any_fire != 0ull) {                  // one branch per wave and step
+#pragma unroll
+            for (int r = 0; r < SL; ++r) {
+                const bool fire = (bal[r] >> lane) & 1ull;
+                if (fire) {
+                    const int rank = nspk + lane_rank(bal[r]);
+                    const uint16_t me = (uint16_t)((w * SL + r) * 64 + lane);
+                    list_cur[rank] = me;
+                    if (rank < R) flist[cur * 64 + w * R + rank] = me;
+                    if (os[r] >= 0) {
+                        uint4 f = feat[os[r]];
+                        uint32_t n = f.x & 0xFFFFu, bursts = f.x >> 16;
+                        uint32_t first = f.y & 0xFFFFu, last = f.y >> 16;
+                        const uint32_t isi = (uint32_t)t - last;
+                        first = n == 0 ? (uint32_t)t : first;
+                        f.w += n == 0 ? 0u : isi * isi;
+                        bursts += (n != 0 && (int)isi <= a.burst_isi_max) ? 1u : 0u;
+                        last = (uint32_t)t;
+                        n += 1;
+                        f.z += (uint32_t)t;
+                        f.x = n | (bursts << 16);
+                        f.y = first | (last << 16);
+                        feat[os[r]] = f;
+                    }
+                }
+                nspk += __popcll(bal[r]);
+            }
+        }
+        if (lane == 0) {
+            wcnt[cur * 16 + w] = (uint32_t)nspk;
+            if (nspk > R) wcnt[32 + f_set] = 1u;         // next step's consumers take the general path
+        }
+        if (trace) {
+#pragma unroll
+            for (int r = 0; r < SL; ++r) {
+                const int i = (w * SL + r) * 64 + lane;
+                if (i < N) {
+                    if (a.spike_matrix)
+                        a.spike_matrix[((size_t)b * T + t) * N + i] = (uint8_t)((bal[r] >> lane) & 1ull);
+                    if (a.v_trace) a.v_trace[((size_t)b * T + t) * N + i] = v[r];
+                }
+            }
+        }
+        __syncthreads();
+    }
+
+    // ---- epilogue: SPEC.md §4 features from the integer accumulators (float64, then float32) ----
+    const int nf = a.n_keys * a.n_out;
+    for (int idx = tid; idx < nf; idx += NT) {
+        const int kq = idx / a.n_out;
+        const int o = idx - kq * a.n_out;
+        const uint4 f = feat[o];
+        const int n = (int)(f.x & 0xFFFFu), bursts = (int)(f.x >> 16);
+        const int first = (int)(f.y & 0xFFFFu), last = (int)(f.y >> 16);
+        double val = 0.0;
+        switch (a.key_ids[kq]) {
+        case 0: val = (double)n; break;
+        case 1: { const double p = (double)n / (double)T; val = p * (1.0 - p); } break;
+        case 2: val = n >= 1 ? (double)f.z / (double)n : 0.0; break;
+        case 3: val = n >= 1 ? (double)first : 0.0; break;
+        case 4: val = n >= 1 ? (double)last : 0.0; break;
+        case 5: val = n >= 2 ? (double)(last - first) / (double)(n - 1) : 0.0; break;
+        case 6:
+            if (n >= 2) {
+                const double m = (double)(last - first) / (double)(n - 1);
+                val = (double)f.w / (double)(n - 1) - m * m;
+            }
+            break;
+        default: val = (double)bursts; break;
+        }
+        a.features[(size_t)b * nf + idx] = (float)val;
+    }
+}
+
+typedef void (*dense_fn_t)(const DenseArgs);
+
+template <int SL, bool INREG>
+dense_fn_t pick_dense_wpc(int wpc)
+{
+    switch (wpc) {
+    case 1: return lif_dense_kernel<SL, 1, INREG>;
+    case 2: return lif_dense_kernel<SL, 2, INREG>;
+    case 4: return lif_dense_kernel<SL, 4, INREG>;
+    case 8: return lif_dense_kernel<SL, 8, INREG>;
+    case 16: return lif_dense_kernel<SL, 16, INREG>;
+    default: return nullptr;
+    }
+}
+
+template <bool INREG>
+dense_fn_t pick_dense_sl(int sl, int wpc)
+{
+    switch (sl) {
+    case 1: return pick_dense_wpc<1, INREG>(wpc);
+    case 2: return pick_dense_wpc<2, INREG>(wpc);
+    case 4: return pick_dense_wpc<4, INREG>(wpc);
+    case 8: return pick_dense_wpc<8, INREG>(wpc);
+    case 16: return pick_dense_wpc<16, INREG>(wpc);
+    default: return nullptr;
+    }
+}
+
+dense_fn_t pick_dense_0(int sl, int wpc);      // lif_dense_0.hip (INREG = false)
+dense_fn_t pick_dense_1(int sl, int wpc);      // lif_dense_1.hip (INREG = true)
+
+}  // namespace lsm_lif

@@ -1,7 +1,7 @@
 // Host side of the reservoir C ABI (include/lsm_hip.h): handle creation (CSC upload, per-layout
 // segment tables), layout choice and kernel launch.  The kernel itself lives in lif_kernel.h and
 // is instantiated by the four lif_variant_*.hip translation units.
-#include "lif_kernel.h"
+#include "lif_dense.h"
 
 #include <algorithm>
 #include <cstring>
@@ -53,6 +53,9 @@ struct lsm_reservoir {
     size_t nnz = 0;
     uint2 *syn = nullptr;
     uint32_t *rowptr = nullptr;
+    float *wt = nullptr;    // dense rows by presynaptic neuron (N, ld), small reservoirs only
+    int ld = 0;
+    int mode = 0;           // 0 auto, 1 sparse (CSC scatter through LDS), 2 dense rows
     Variant var[5];         // wpc = 1, 2, 4, 8, 16 (wpc == 0: not available)
 };
 
@@ -61,6 +64,7 @@ static int free_reservoir(lsm_reservoir *h)
     if (!h) return LSM_OK;
     if (h->syn) (void)hipFree(h->syn);
     if (h->rowptr) (void)hipFree(h->rowptr);
+    if (h->wt) (void)hipFree(h->wt);
     for (auto &v : h->var) {
         if (v.seg) (void)hipFree(v.seg);
         if (v.segoff) (void)hipFree(v.segoff);
@@ -180,7 +184,30 @@ int lsm_reservoir_create(lsm_reservoir **out, int num_neurons, int n_channels,
         }
         v.wpc = wpc; v.sl = sl; v.einw = einw;
     }
+    // dense presynaptic rows for the register-accumulating kernel (lif_dense.h): N x ld floats, only
+    // while that stays small enough for L2 / Infinity Cache (N <= 2048: <= 16 MB)
+    if (N <= 2048) {
+        int ldmax = 0;
+        for (const auto &v : h->var)
+            if (v.wpc) ldmax = std::max(ldmax, v.sl * 64 * v.wpc);
+        std::vector<float> wt((size_t)N * ldmax, 0.0f);
+        for (int j = 0; j < N; ++j)
+            for (int e = csc_ptr[j]; e < csc_ptr[j + 1]; ++e) wt[(size_t)j * ldmax + csc_post[e]] = csc_w[e];
+        if ((rc = upload(&h->wt, wt))) { free_reservoir(h); return rc; }
+        h->ld = ldmax;
+    }
     *out = h;
+    return LSM_OK;
+}
+
+// 0 = choose (dense rows when the table exists), 1 = sparse CSC kernel, 2 = dense-row kernel.
+extern "C" __attribute__((visibility("default")))
+int lsm_reservoir_set_kernel(lsm_reservoir *h, int mode)
+{
+    LSM_REQUIRE(h != nullptr, "lsm_reservoir_set_kernel: null handle");
+    LSM_REQUIRE(mode >= 0 && mode <= 2, "mode must be 0 (auto), 1 (sparse) or 2 (dense)");
+    LSM_REQUIRE(mode != 2 || h->wt != nullptr, "dense rows are only built for reservoirs of <= 2048 neurons");
+    h->mode = mode;
     return LSM_OK;
 }
 
@@ -213,6 +240,15 @@ static size_t lif_lds_bytes(const lsm_reservoir *h, const Variant &v, int T)
     return lif_lds_core(h, v, T) + (lif_seg_in_lds(h, v, T) ? lif_seg_bytes(h, v) : 0);
 }
 
+static bool use_dense(const lsm_reservoir *h) { return h->wt != nullptr && h->mode != 1; }
+
+static size_t dense_lds_bytes(const lsm_reservoir *h, const Variant &v, int T)
+{
+    const size_t npad = (size_t)v.sl * 64 * v.wpc;
+    const size_t cw = (size_t)(h->C + 31) / 32;
+    return npad * 4 + 2 * npad * 2 + 512 + (size_t)h->n_out * 16 + (size_t)T * cw * 4;
+}
+
 // Pick the waves-per-clip layout.  Measured on MI355X at N=1000 (profiles/): the best layout has
 // about 4096 wavefronts in flight (B=256 -> 16, B=512 -> 8) and never fewer than 4 waves per clip
 // (B=4096: 4 waves 9.1 ms, 2 waves 10.6 ms, 1 wave 17.6 ms).  Among the layouts this reservoir
@@ -225,7 +261,10 @@ static const Variant *choose_variant(const lsm_reservoir *h, int B, int T, int r
         return nullptr;
     }
     int target = 4;
-    while (target < 16 && (long)B * target < 4096) target <<= 1;
+    // dense-row kernel (measured at N=1000, B=256: 4 waves 0.82 ms, 8 waves 0.75 ms, 16 waves 0.81 ms):
+    // about 2048 wavefronts; sparse kernel: about 4096
+    const long want = use_dense(h) ? 2048 : 4096;
+    while (target < 16 && (long)B * target < want) target <<= 1;
     // large reservoirs: more waves per clip keep the per-lane neuron slots (registers, update work per
     // wave) small -- N=4000, B=1024: 4 waves 68 ms, 8 waves 43 ms, 16 waves 26 ms
     const Variant *best = nullptr;
@@ -247,13 +286,38 @@ int lsm_reservoir_run(const lsm_reservoir *h, const uint8_t *spikes_u8, int n_cl
     LSM_REQUIRE(n_keys >= 1 && n_keys <= 8 && key_ids, "n_keys must be in [1, 8]");
     if (n_clips == 0) return LSM_OK;            // empty batch: nothing to read or write
     LSM_REQUIRE(spikes_u8 && features_out, "null buffer");
+
+    const Variant *v = choose_variant(h, n_clips, n_steps, waves_per_clip);
+    LSM_REQUIRE(v != nullptr, "no reservoir layout for waves_per_clip=%d (N=%d, T=%d)",
+                waves_per_clip, h->N, n_steps);
     int dev_now = -1;
     LSM_CHECK_HIP(hipGetDevice(&dev_now));
     LSM_REQUIRE(dev_now == h->device, "reservoir handle lives on device %d but the current device is %d",
                 h->device, dev_now);
-    const Variant *v = choose_variant(h, n_clips, n_steps, waves_per_clip);
-    LSM_REQUIRE(v != nullptr, "no reservoir layout for waves_per_clip=%d (N=%d, T=%d)",
-                waves_per_clip, h->N, n_steps);
+    for (int k = 0; k < n_keys; ++k)
+        LSM_REQUIRE(key_ids[k] >= 0 && key_ids[k] < 8, "key id %d out of range", key_ids[k]);
+    if (use_dense(h)) {
+        lsm_lif::dense_fn_t dfn = lif_inreg(*v) ? lsm_lif::pick_dense_1(v->sl, v->wpc)
+                                                : lsm_lif::pick_dense_0(v->sl, v->wpc);
+        LSM_REQUIRE(dfn != nullptr, "no dense kernel for SL=%d WPC=%d", v->sl, v->wpc);
+        lsm_lif::DenseArgs d;
+        d.N = h->N; d.C = h->C; d.T = n_steps; d.B = n_clips;
+        d.n_out = h->n_out; d.CW = (h->C + 31) / 32; d.EinW = v->einw;
+        d.refractory = h->refractory; d.burst_isi_max = h->burst_isi_max; d.ld = h->ld;
+        d.theta = h->theta; d.w_in = h->w_in;
+        d.raster = spikes_u8; d.wt = h->wt; d.leak = v->leak; d.oslot = v->oslot; d.in_ent = v->in_ent;
+        d.n_keys = n_keys;
+        for (int k = 0; k < 8; ++k) d.key_ids[k] = k < n_keys ? key_ids[k] : 0;
+        d.features = features_out; d.spike_matrix = spike_matrix_out; d.v_trace = v_trace_out;
+        const size_t dlds = dense_lds_bytes(h, *v, n_steps);
+        LSM_REQUIRE(dlds <= 160 * 1024, "dense layout needs %zu bytes of LDS", dlds);
+        if (dlds > 64 * 1024)
+            LSM_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(dfn),
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)dlds));
+        hipLaunchKernelGGL(dfn, dim3(n_clips), dim3(v->wpc * 64), dlds, (hipStream_t)stream, d);
+        LSM_CHECK_HIP(hipGetLastError());
+        return LSM_OK;
+    }
     lif_fn_t fn = pick_kernel(v->sl, v->wpc, lif_inreg(*v), lif_seg_in_lds(h, *v, n_steps));
     LSM_REQUIRE(fn != nullptr, "no kernel for SL=%d WPC=%d", v->sl, v->wpc);
 

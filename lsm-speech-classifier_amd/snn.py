@@ -114,6 +114,11 @@ class SNN:
             "mean_spikes_per_neuron": total / self.num_neurons,
         }
 
+    def set_kernel(self, mode: str = "auto"):
+        """'auto' (dense presynaptic rows for N <= 2048, else sparse), 'sparse' or 'dense'."""
+        _lib.check(self.lib.lsm_reservoir_set_kernel(self._handle, {"auto": 0, "sparse": 1, "dense": 2}[mode]),
+                   "lsm_reservoir_set_kernel")
+
     def layout(self, n_clips: int, n_steps: int, waves_per_clip: int = 0):
         wpc, sl, lds = C.c_int(), C.c_int(), C.c_int()
         _lib.check(self.lib.lsm_reservoir_layout(self._handle, n_clips, n_steps, waves_per_clip,

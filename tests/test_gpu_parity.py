@@ -159,9 +159,11 @@ def test_reservoir_matches_oracle_all_layouts(torch_cuda, oracle_c, n, k, n_out,
     rasters[2] = synth.bernoulli_raster(1, c, 400, 0.05, seed=n + 1)[0]
     res = _reservoir(n, k, n_out, c, rasters)
     net = snn.SNN(None, reservoir=res)
-    for wpc in wpcs:
-        total = _check_against_oracle(net, rasters, oracle_c, wpc)
-        assert total > 0, "test input must make the reservoir spike"
+    for kernel in ("dense", "sparse"):                   # both kernels, every layout
+        net.set_kernel(kernel)
+        for wpc in wpcs:
+            total = _check_against_oracle(net, rasters, oracle_c, wpc)
+            assert total > 0, "test input must make the reservoir spike"
 
 
 def test_reservoir_edge_cases(torch_cuda, oracle_c):
@@ -179,9 +181,12 @@ def test_reservoir_edge_cases(torch_cuda, oracle_c):
         res = _reservoir(130, 20, 130, c, base, multiplier=mult, refractory_period=refr,
                          leak_variance_divisor=div)
         net = snn.SNN(None, reservoir=res)
-        for name, r in cases.items():
-            for wpc in (1, 2):
-                _check_against_oracle(net, r, oracle_c, wpc)
+        for kernel in ("dense", "sparse"):
+            net.set_kernel(kernel)
+            for name, r in cases.items():
+                for wpc in (1, 2):
+                    _check_against_oracle(net, r, oracle_c, wpc)
+        net.set_kernel("auto")
     silent_feats, sm, _ = net.run_batch(cases["silent"], want_spike_matrix=True)
     assert int(sm.sum()) == 0 and not silent_feats.cpu().numpy().any()
     # empty batch is a no-op
@@ -238,9 +243,12 @@ def test_full_size_properties(torch_cuda, oracle_c):
     perm = np.random.RandomState(0).permutation(B)                       # batch order independence
     f2, _, _ = net.run_batch(dev[torch.from_numpy(perm).cuda()], waves_per_clip=0)
     np.testing.assert_array_equal(f2.cpu().numpy(), f[perm])
-    for wpc in (1, 4, 16):                                               # layouts agree
-        fw, _, _ = net.run_batch(dev, waves_per_clip=wpc)
-        np.testing.assert_array_equal(fw.cpu().numpy(), f)
+    for kernel in ("sparse", "dense"):                                   # kernels and layouts agree
+        net.set_kernel(kernel)
+        for wpc in (1, 4, 16):
+            fw, _, _ = net.run_batch(dev, waves_per_clip=wpc)
+            np.testing.assert_array_equal(fw.cpu().numpy(), f)
+    net.set_kernel("auto")
     ref = oracle_c.lif_run_batch(res, rasters[:6], n_threads=6)
     np.testing.assert_array_equal(f[:6], ref)
 
@@ -259,3 +267,5 @@ def test_large_reservoirs_match_oracle(torch_cuda, oracle_c, n, k, n_out, c, cli
     for wpc in (0, 8):
         feats, _, _ = net.run_batch(rasters, keys, waves_per_clip=wpc)
         np.testing.assert_array_equal(feats.cpu().numpy(), ref)
+    with pytest.raises(Exception, match="dense rows"):   # too large for the dense-row kernel
+        net.set_kernel("dense")
