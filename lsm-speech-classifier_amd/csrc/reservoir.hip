@@ -356,7 +356,8 @@ int lsm_reservoir_layout(const lsm_reservoir *h, int n_clips, int n_steps, int w
     LSM_REQUIRE(v != nullptr, "no reservoir layout for waves_per_clip=%d", waves_per_clip);
     if (wpc_out) *wpc_out = v->wpc;
     if (slots_out) *slots_out = v->sl;
-    if (lds_bytes_out) *lds_bytes_out = (int)lif_lds_bytes(h, *v, n_steps);
+    if (lds_bytes_out)
+        *lds_bytes_out = (int)(use_dense(h) ? dense_lds_bytes(h, *v, n_steps) : lif_lds_bytes(h, *v, n_steps));
     return LSM_OK;
 }
 
