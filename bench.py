@@ -308,7 +308,7 @@ def main():
             if os.path.exists(tfile):
                 traffic = json.load(open(tfile)).get(f"{args.config}_B{B}")
             line["roofline"] = {
-                "bound": "hbm", "kernel": "lif_dense_kernel" if cfg["N"] <= 2048 else "lif_kernel", "achieved": round(achieved, 2),
+                "bound": "hbm", "kernel": "lif_dense_kernel" if cfg["N"] <= 8192 else "lif_kernel", "achieved": round(achieved, 2),
                 "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
                 "traffic": traffic, "kernel_ms": round(lif_ms, 4),
                 "bytes_per_clip": round(per_clip, 1),

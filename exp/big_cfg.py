@@ -17,6 +17,7 @@ wc = bench.w_critico(cfg["k"], 2.0, 2, r)
 p = R.SimulationParams(num_neurons=cfg["N"], num_output_neurons=cfg["n_out"], small_world_graph_k=cfg["k"], mean_weight=wc * 0.6)
 t0 = time.time(); res = R.build_reservoir(p, fe.n_channels); print(f"reservoir built nnz={res.nnz} ({time.time()-t0:.1f}s)", flush=True)
 net = snn.SNN(p, reservoir=res)
+net.set_kernel(os.environ.get('LSM_KERNEL', 'auto'))
 print("layout", net.layout(B, 400), flush=True)
 for wpc in ([0] if len(sys.argv) < 5 else [int(x) for x in sys.argv[4].split(",")]):
     f, _, _ = net.run_batch(r, bench.FEATURE_SET, waves_per_clip=wpc); torch.cuda.synchronize()

@@ -1,9 +1,9 @@
-// lif_dense.h -- LIF reservoir time loop for SMALL reservoirs (dense presynaptic rows), gfx950.
+// lif_dense.h -- LIF reservoir time loop on dense presynaptic rows (N <= 8192), gfx950.
 //
 // Same contract as lif_kernel.h (SPEC.md §3-§4; replaces reset/set_input_spike_times/simulate/
 // extract_features_from_spikes of /root/reference/extract_lsm_features.py:79-83), different data
 // structure: W is stored as dense rows by PRESYNAPTIC neuron, Wt[j][i] (0 where there is no synapse),
-// N x LD floats = 4 MB at N = 1000, which lives in L2 / Infinity Cache.  For every neuron j that spiked
+// N x LD floats: 4 MB at N = 1000 (L2 resident), 64 MB at N = 4000 (Infinity Cache), 262 MB at N = 8000.  For every neuron j that spiked
 // at t-1, ascending, each lane loads the weight onto ITS OWN target neuron (one coalesced 256-byte load
 // per wave and 64-neuron slot) and adds it to a REGISTER accumulator.  The oracle's per-target sum runs
 // over the existing synapses in ascending j; the extra terms here are exact zeros and x + 0 = x in
@@ -46,7 +46,7 @@ __global__ __launch_bounds__(WPC * 64) void lif_dense_kernel(const DenseArgs a)
     constexpr int NPAD = NPW * WPC;
     constexpr int NT = WPC * 64;
     constexpr int R = 64 / WPC;            // fixed-region list entries per producer wave
-    constexpr int G = 16 / SL;             // rows in flight per group (G*SL = 16 registers)
+    constexpr int G = SL == 1 ? 16 : 32 / SL;   // rows in flight per group (<= 32 registers of weights)
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint32_t *icnt = reinterpret_cast<uint32_t *>(smem);                              // NPAD

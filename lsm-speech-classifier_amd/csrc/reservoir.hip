@@ -186,7 +186,7 @@ int lsm_reservoir_create(lsm_reservoir **out, int num_neurons, int n_channels,
     }
     // dense presynaptic rows for the register-accumulating kernel (lif_dense.h): N x ld floats, only
     // while that stays small enough for L2 / Infinity Cache (N <= 2048: <= 16 MB)
-    if (N <= 2048) {
+    if (N <= 8192) {
         int ldmax = 0;
         for (const auto &v : h->var)
             if (v.wpc) ldmax = std::max(ldmax, v.sl * 64 * v.wpc);
@@ -206,7 +206,7 @@ int lsm_reservoir_set_kernel(lsm_reservoir *h, int mode)
 {
     LSM_REQUIRE(h != nullptr, "lsm_reservoir_set_kernel: null handle");
     LSM_REQUIRE(mode >= 0 && mode <= 2, "mode must be 0 (auto), 1 (sparse) or 2 (dense)");
-    LSM_REQUIRE(mode != 2 || h->wt != nullptr, "dense rows are only built for reservoirs of <= 2048 neurons");
+    LSM_REQUIRE(mode != 2 || h->wt != nullptr, "dense rows are only built for reservoirs of <= 8192 neurons");
     h->mode = mode;
     return LSM_OK;
 }

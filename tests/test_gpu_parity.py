@@ -264,8 +264,8 @@ def test_large_reservoirs_match_oracle(torch_cuda, oracle_c, n, k, n_out, c, cli
     keys = ["spike_counts", "spike_variances", "mean_spike_times", "mean_isi", "isi_variances"]
     ref = oracle_c.lif_run_batch(res, rasters, keys, n_threads=clips)
     assert ref[:, :n_out].sum() > 0
-    for wpc in (0, 8):
-        feats, _, _ = net.run_batch(rasters, keys, waves_per_clip=wpc)
-        np.testing.assert_array_equal(feats.cpu().numpy(), ref)
-    with pytest.raises(Exception, match="dense rows"):   # too large for the dense-row kernel
-        net.set_kernel("dense")
+    for kernel in ("dense", "sparse"):                   # 64 MB / 262 MB dense tables vs the CSC scatter
+        net.set_kernel(kernel)
+        for wpc in (0, 8):
+            feats, _, _ = net.run_batch(rasters, keys, waves_per_clip=wpc)
+            np.testing.assert_array_equal(feats.cpu().numpy(), ref, err_msg=f"{kernel} wpc {wpc}")
