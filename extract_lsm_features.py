@@ -59,8 +59,9 @@ def load_spike_dataset(filename=DATASET_FILE):
     if not Path(filename).exists():
         print(f"Error: Dataset not found at '{filename}'")
         return None, None
-    with np.load(filename) as data:
-        X_spikes, y_labels = data['X_spikes'], data['y_labels']
+    # the reference's uint8 schema or the bit-packed one; either way the reference's arrays come back
+    from lsm_speech_classifier_amd import spikefile
+    X_spikes, y_labels = spikefile.load(filename)
     print(f"Loaded {len(X_spikes)} samples from '{filename}'")
     return X_spikes, y_labels
 

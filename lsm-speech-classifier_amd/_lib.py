@@ -28,6 +28,8 @@ _SIGS = {
     "lsm_power_to_db_f32": (c_int, [c_void, c_int, c_int, c_float, c_float, c_void, c_void]),
     "lsm_encode_hysteresis_f64": (c_int, [c_void, c_int, c_int, c_void, c_void, c_int, c_void, c_void]),
     "lsm_encode_hysteresis_f32": (c_int, [c_void, c_int, c_int, c_void, c_void, c_int, c_void, c_void]),
+    "lsm_raster_pack_bits": (c_int, [c_void, C.c_long, c_int, c_void, c_void]),
+    "lsm_raster_unpack_bits": (c_int, [c_void, C.c_long, c_int, c_void, c_void]),
     "lsm_reservoir_create": (c_int, [C.POINTER(c_void), c_int, c_int, c_void, c_void, c_void, c_void,
                                      c_void, c_int, c_float, c_void, c_int, c_float, c_int, c_int]),
     "lsm_reservoir_destroy": (c_int, [c_void]),

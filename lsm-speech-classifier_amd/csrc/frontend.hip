@@ -345,6 +345,52 @@ int launch_encode(const T *spec, int n_rows, int n_bins, const T *thr_on, const 
     return LSM_OK;
 }
 
+// Bit-packed rasters (File 1, packed variant): byte q of a row holds time steps 8q..8q+7, step 8q+k in
+// bit k.  One thread per packed byte; rows whose length is a multiple of 8 move 8 raster bytes per
+// thread as one 64-bit access (a wave then touches 512 contiguous raster bytes and 64 packed ones).
+__global__ __launch_bounds__(256) void pack_bits_kernel(const uint8_t *__restrict__ raster,
+                                                        long n_rows, int T, int TP,
+                                                        uint8_t *__restrict__ packed)
+{
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n_rows * TP) return;
+    const long r = i / TP;
+    const int q = (int)(i - r * TP);
+    const uint8_t *src = raster + r * T + (long)q * 8;
+    uint32_t byte = 0;
+    if ((T & 7) == 0) {
+        const uint2 v = *reinterpret_cast<const uint2 *>(src);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            byte |= ((v.x >> (8 * k)) & 0xFFu) ? (1u << k) : 0u;
+            byte |= ((v.y >> (8 * k)) & 0xFFu) ? (1u << (k + 4)) : 0u;
+        }
+    } else {
+        for (int k = 0; k < 8 && q * 8 + k < T; ++k) byte |= src[k] ? (1u << k) : 0u;
+    }
+    packed[i] = (uint8_t)byte;
+}
+
+__global__ __launch_bounds__(256) void unpack_bits_kernel(const uint8_t *__restrict__ packed,
+                                                          long n_rows, int T, int TP,
+                                                          uint8_t *__restrict__ raster)
+{
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n_rows * TP) return;
+    const long r = i / TP;
+    const int q = (int)(i - r * TP);
+    const uint32_t byte = packed[i];
+    uint8_t *dst = raster + r * T + (long)q * 8;
+    if ((T & 7) == 0) {
+        uint2 v;
+        v.x = (byte & 1u) | ((byte & 2u) << 7) | ((byte & 4u) << 14) | ((byte & 8u) << 21);
+        v.y = ((byte >> 4) & 1u) | ((byte & 32u) << 3) | ((byte & 64u) << 10) | ((byte & 128u) << 17);
+        *reinterpret_cast<uint2 *>(dst) = v;
+    } else {
+        for (int k = 0; k < 8 && q * 8 + k < T; ++k) dst[k] = (uint8_t)((byte >> k) & 1u);
+    }
+}
+
 }  // namespace
 
 // CU count and LDS per CU of the current device (queried once per device)
@@ -476,4 +522,40 @@ LSM_API int lsm_encode_hysteresis_f32(const float *spec, int n_rows, int n_bins,
                                       uint8_t *out, void *stream)
 {
     return launch_encode<float>(spec, n_rows, n_bins, thr_on, thr_off, n_thr, out, stream);
+}
+
+static int check_bits_args(const void *a, const void *b, long n_rows, int T, const char *what)
+{
+    LSM_REQUIRE(n_rows >= 0 && T >= 1, "%s: bad shape", what);
+    if (n_rows == 0) return 1;
+    LSM_REQUIRE(a && b, "%s: null buffer", what);
+    LSM_REQUIRE(((uintptr_t)a & 7u) == 0 && ((uintptr_t)b & 7u) == 0, "%s: buffers must be 8-byte aligned", what);
+    LSM_REQUIRE(n_rows * (long)((T + 7) / 8) <= 0x7fffffffL * 256L, "%s: too many rows", what);
+    return LSM_OK;
+}
+
+LSM_API int lsm_raster_pack_bits(const uint8_t *raster, long n_rows, int n_steps, uint8_t *packed,
+                                 void *stream)
+{
+    const int rc = check_bits_args(raster, packed, n_rows, n_steps, "pack_bits");
+    if (rc != LSM_OK) return rc == 1 ? LSM_OK : rc;
+    const int TP = (n_steps + 7) / 8;
+    const long n = n_rows * TP;
+    hipLaunchKernelGGL(pack_bits_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0,
+                       (hipStream_t)stream, raster, n_rows, n_steps, TP, packed);
+    LSM_CHECK_HIP(hipGetLastError());
+    return LSM_OK;
+}
+
+LSM_API int lsm_raster_unpack_bits(const uint8_t *packed, long n_rows, int n_steps, uint8_t *raster,
+                                   void *stream)
+{
+    const int rc = check_bits_args(packed, raster, n_rows, n_steps, "unpack_bits");
+    if (rc != LSM_OK) return rc == 1 ? LSM_OK : rc;
+    const int TP = (n_steps + 7) / 8;
+    const long n = n_rows * TP;
+    hipLaunchKernelGGL(unpack_bits_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0,
+                       (hipStream_t)stream, packed, n_rows, n_steps, TP, raster);
+    LSM_CHECK_HIP(hipGetLastError());
+    return LSM_OK;
 }

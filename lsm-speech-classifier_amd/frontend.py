@@ -240,3 +240,35 @@ def convert_spectrogram_to_spikes_hysteresis(spectrogram, thresholds, hysteresis
 def create_pure_redundancy(spike_train: np.ndarray, redundancy_factor: int) -> np.ndarray:
     """create_dataset.py:101-104 (host copy; the batched path repeats rows inside the kernel)."""
     return np.repeat(spike_train, redundancy_factor, axis=0)
+
+
+# ---- bit-packed rasters: the packed variant of File 1 (SURVEY.md §8f-4) --------------------------
+
+def pack_raster(raster: torch.Tensor) -> torch.Tensor:
+    """(..., T) uint8 on the GPU (any non-zero byte is a spike) -> (..., ceil(T/8)) uint8, time step
+    8q+k in bit k of byte q (``numpy.packbits(x != 0, axis=-1, bitorder="little")``)."""
+    _lib.require_gpu()
+    if raster.dtype != torch.uint8 or not raster.is_cuda:
+        raise ValueError("pack_raster: expected a uint8 CUDA tensor")
+    raster = raster.contiguous()
+    T = raster.shape[-1]
+    rows = raster.numel() // T if T else 0
+    out = torch.empty(raster.shape[:-1] + ((T + 7) // 8,), dtype=torch.uint8, device=raster.device)
+    _lib.check(_lib.load().lsm_raster_pack_bits(_dev(raster), rows, T, _dev(out), _stream()),
+               "lsm_raster_pack_bits")
+    return out
+
+
+def unpack_raster(packed: torch.Tensor, n_steps: int) -> torch.Tensor:
+    """Inverse of :func:`pack_raster`: (..., ceil(T/8)) uint8 on the GPU -> (..., T) bytes of 0/1."""
+    _lib.require_gpu()
+    if packed.dtype != torch.uint8 or not packed.is_cuda:
+        raise ValueError("unpack_raster: expected a uint8 CUDA tensor")
+    if packed.shape[-1] != (n_steps + 7) // 8:
+        raise ValueError(f"unpack_raster: last dimension {packed.shape[-1]} does not hold {n_steps} steps")
+    packed = packed.contiguous()
+    rows = packed.numel() // packed.shape[-1] if packed.shape[-1] else 0
+    out = torch.empty(packed.shape[:-1] + (n_steps,), dtype=torch.uint8, device=packed.device)
+    _lib.check(_lib.load().lsm_raster_unpack_bits(_dev(packed), rows, n_steps, _dev(out), _stream()),
+               "lsm_raster_unpack_bits")
+    return out

@@ -74,14 +74,19 @@ class SNN:
 
     # ---- batched path -------------------------------------------------------------------
     def run_batch(self, spikes, feature_keys=None, want_spike_matrix=False, want_v_trace=False,
-                  waves_per_clip: int = 0):
+                  waves_per_clip: int = 0, packed_time_steps: int = 0):
         """spikes: uint8 (B, C, T) torch tensor on this device (or NumPy, copied).  Returns
         (features float32 (B, n_keys*N_out) device tensor, spike_matrix or None, v_trace or None);
         NaN entries are already 0 and keys are concatenated in the given order
-        (extract_lsm_features.py:85-87)."""
+        (extract_lsm_features.py:85-87).  With ``packed_time_steps=T`` the input is the bit-packed
+        form (B, C, ceil(T/8)) of ``spikefile``: it is uploaded as it is and unpacked on the GPU."""
         if isinstance(spikes, np.ndarray):
             spikes = torch.from_numpy(np.ascontiguousarray(spikes, dtype=np.uint8))
         spikes = spikes.to(self.device, dtype=torch.uint8).contiguous()
+        if packed_time_steps:
+            from .frontend import unpack_raster
+            with torch.cuda.device(self.device):
+                spikes = unpack_raster(spikes, int(packed_time_steps))
         if spikes.dim() != 3 or spikes.shape[1] != self.n_channels:
             raise ValueError(f"spikes must be (B, {self.n_channels}, T), got {tuple(spikes.shape)}")
         B, _, T = spikes.shape
