@@ -323,16 +323,17 @@ def main():
                 round(per_clip * B / (serial_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
             }
         if fe_ms is not None and cfg["filterbank"] == "gammatone":
-            # front end alone on an idle GPU: float64 VALU-issue bound (35 operations per sample and
+            # front end alone on an idle GPU: float64 VALU-issue bound (36 instructions per sample and
             # channel, none of them fusable into FMAs without changing the rounding), not HBM bound
-            ops = 35.0 * ((fe.ncols - 1) * fe.hop + fe.nwin) * cfg["n_filters"] * B
+            ops = 36.0 * ((fe.ncols - 1) * fe.hop + fe.nwin) * cfg["n_filters"] * B
+            gt_waves = -(-cfg["n_filters"] // 64) * B
             line["frontend"] = {
                 "kernels": "gammatone_kernel + spec_to_spikes_kernel", "idle_gpu_ms": round(fe_ms, 4),
                 "bound": "valu_f64", "achieved_tflops": round(ops / (fe_ms * 1e-3) / 1e12, 2),
                 "peak_tflops_fma_counted": 78.6, "peak_tops_unfused": 39.3,
                 "note": "one float64 operation per lane and instruction (no FMA contraction allowed): the "
-                        "ceiling for this instruction mix is 39.3 Tops/s with all 1024 SIMDs busy; the "
-                        "launch has 512 waves at this batch",
+                        "ceiling for this instruction mix is 39.3 Tops/s with all 1024 SIMDs busy and >= 4 "
+                        f"waves per SIMD (exp/ubench_f64.hip); this launch has {gt_waves} waves",
             }
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(cfg, audio_np, res)
