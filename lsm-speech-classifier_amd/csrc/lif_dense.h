@@ -21,6 +21,11 @@
 #pragma once
 #include "lif_kernel.h"
 
+#ifndef LSM_ABLATE
+#define LSM_ABLATE 0        // diagnostic builds only (results are WRONG): 1 = no recurrent rows, 2 = no input
+#endif                      // drive, 4 = no step barrier, 8 = no feature updates, 16 = no loads (adds kept),
+                            // 32 = rows folded onto the first 256 (1 MB footprint), 64 = non-temporal raster reads
+
 namespace lsm_lif {
 
 struct DenseArgs {
@@ -74,7 +79,7 @@ __global__ __launch_bounds__(WPC * 64) void lif_dense_kernel(const DenseArgs a)
             const uint32_t *clip4 = reinterpret_cast<const uint32_t *>(clip);
             const int nd = a.C * T / 4;
             for (int q = tid; q < nd; q += NT) {
-                const uint32_t v = clip4[q];
+                const uint32_t v = (LSM_ABLATE & 64) ? __builtin_nontemporal_load(clip4 + q) : clip4[q];
                 if (v == 0) continue;
                 const int c = (q * 4) / T;
                 const int t0 = (q * 4) - c * T;
@@ -125,6 +130,7 @@ __global__ __launch_bounds__(WPC * 64) void lif_dense_kernel(const DenseArgs a)
 
     // input drive of step `ts`: count the active channels feeding each target (integer atomics)
     auto input_drive = [&](int ts) {
+        if (LSM_ABLATE & 2) return;
         const uint32_t *row = bits + ts * CW;
         if (INREG) {
 #pragma unroll
@@ -162,6 +168,8 @@ __global__ __launch_bounds__(WPC * 64) void lif_dense_kernel(const DenseArgs a)
         // (G = 16/SL) are in flight; nested "one more?" tests make a group cost one taken branch.
         bool drove = false;
         auto add_rows = [&](unsigned long long todo, uint32_t jl) {
+            if (LSM_ABLATE & 1) todo = 0ull;
+            if (LSM_ABLATE & 4) jl = min(jl, (uint32_t)(N - 1));
             while (todo != 0ull) {
                 const int n8 = min((int)__popcll(todo), G);
                 float wv[16][SL];                   // only the first G rows are ever live
@@ -170,8 +178,9 @@ __global__ __launch_bounds__(WPC * 64) void lif_dense_kernel(const DenseArgs a)
         const int sk = __builtin_ctzll(todo);                                       \
         todo &= todo - 1ull;                                                        \
         const uint32_t j = __builtin_amdgcn_readlane(jl, sk);                       \
-        const float *rowp = wt_mine + (size_t)j * ld;                               \
-        _Pragma("unroll") for (int r = 0; r < SL; ++r) wv[k][r] = rowp[r * 64];     \
+        const float *rowp = wt_mine + (size_t)((LSM_ABLATE & 32) ? (j & 255u) : j) * ld; \
+        _Pragma("unroll") for (int r = 0; r < SL; ++r)                              \
+            wv[k][r] = (LSM_ABLATE & 16) ? __uint_as_float(j + r) : rowp[r * 64];   \
     }
                 LSM_LD(0)
                 if (n8 > 1) { LSM_LD(1)
@@ -276,7 +285,7 @@ __global__ __launch_bounds__(WPC * 64) void lif_dense_kernel(const DenseArgs a)
                     const uint16_t me = (uint16_t)((w * SL + r) * 64 + lane);
                     list_cur[rank] = me;
                     if (rank < R) flist[cur * 64 + w * R + rank] = me;
-                    if (os[r] >= 0) {
+                    if (os[r] >= 0 && !(LSM_ABLATE & 8)) {
                         uint4 f = feat[os[r]];
                         uint32_t n = f.x & 0xFFFFu, bursts = f.x >> 16;
                         uint32_t first = f.y & 0xFFFFu, last = f.y >> 16;
@@ -310,7 +319,7 @@ __global__ __launch_bounds__(WPC * 64) void lif_dense_kernel(const DenseArgs a)
                 }
             }
         }
-        __syncthreads();
+        if (!(LSM_ABLATE & 4)) __syncthreads();
     }
 
     // ---- epilogue: SPEC.md §4 features from the integer accumulators (float64, then float32) ----
