@@ -23,6 +23,11 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
+# The steps rotate over several HIP streams; the runtime multiplexes streams onto 4 hardware queues by
+# default and kernels of streams that share a queue serialise.  Eight queues let six streams overlap
+# (measured at cfg2: 0.96 -> 0.82 ms per step; exp/hwq_sweep.sh).  Must be set before HIP initialises.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
 import numpy as np
 import torch
 
@@ -105,14 +110,14 @@ def cpu_baseline(cfg, audio, res, seconds_budget=20.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=12)
     ap.add_argument("--config", default="cfg2", choices=sorted(CONFIGS))
     ap.add_argument("--batch", type=int, default=0, help="clips per GPU (0 = the config's)")
     ap.add_argument("--waves-per-clip", type=int, default=0)
     ap.add_argument("--stage", default="full", choices=["full", "reservoir", "frontend"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--streams", type=int, default=3,
+    ap.add_argument("--streams", type=int, default=6,
                     help="HIP streams the steps rotate over (consecutive steps overlap; 1 = serial)")
     ap.add_argument("--pipeline", default="rotate", choices=["rotate", "split"],
                     help="rotate: whole steps round-robin over --streams streams; split: one stream for "
@@ -293,7 +298,8 @@ def main():
                        "small_world_k": cfg["k"], "num_output_neurons": cfg["n_out"],
                        "time_steps": fe.n_steps, "feature_set": "original",
                        "waves_per_clip": lay["waves_per_clip"], "lds_bytes_per_clip": lay["lds_bytes"],
-                       "streams": n_streams, "pipeline": args.pipeline if n_streams > 1 else "serial",
+                       "streams": n_streams, "hw_queues": int(os.environ["GPU_MAX_HW_QUEUES"]),
+                       "pipeline": args.pipeline if n_streams > 1 else "serial",
                        "mean_output_spikes_per_clip": spikes_per_clip,
                        "sharding": f"clips x{world}, feature all-gather" if world > 1 else "single GPU"},
         }
