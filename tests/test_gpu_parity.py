@@ -57,6 +57,41 @@ def test_gammatone_frontend_matches_oracle(torch_cuda, oracle_c, n_filters):
         assert raster[b].dtype == np.uint8 and raster[b].shape == (n_filters, 400)
 
 
+@pytest.mark.parametrize("n_filters,n_clips", [(40, 3), (40, 5), (130, 3), (64, 1)])
+def test_gammatone_partial_workgroups(torch_cuda, oracle_c, n_filters, n_clips):
+    """Wave counts that do not fill the last 4-wave workgroup, and a channel count whose last wave has
+    only two live lanes: every (clip, channel) still equals the oracle bit for bit."""
+    from lsm_speech_classifier_amd import frontend
+    from oracle import ref_numpy as O
+    audio = _mixed_audio(n_clips, seed=3 * n_filters + n_clips)
+    fe = frontend.SpikeFrontEnd(n_filters, "gammatone")
+    coefs = O.gammatone_coefs(16000, n_filters, 50)
+    _, spec = fe.spectrogram_db(audio, want_spec=True)
+    spec = spec.cpu().numpy()
+    assert spec.shape == (n_clips, n_filters, 98)
+    for b in range(n_clips):
+        np.testing.assert_array_equal(spec[b], oracle_c.gammatone_spec(audio[b], coefs, 400, 160, 98))
+
+
+def test_gammatone_large_launch_equals_small_launches(torch_cuda):
+    """More workgroups than CUs (no CU-exclusive LDS reservation) must give the same bits as the small
+    launches that carry the reservation: 600 clips tiled from 5 distinct ones."""
+    import torch
+    from lsm_speech_classifier_amd import frontend
+    base = _mixed_audio(5, seed=77)
+    fe = frontend.SpikeFrontEnd(128, "gammatone")
+    db_small, spec_small = fe.spectrogram_db(base, want_spec=True)
+    reps = 120
+    big = np.tile(base, (reps, 1))
+    db_big, spec_big = fe.spectrogram_db(big, want_spec=True)
+    assert spec_big.shape == (5 * reps, 128, 98)
+    assert torch.equal(spec_big.view(reps, 5, 128, 98), spec_small.unsqueeze(0).expand(reps, -1, -1, -1))
+    assert torch.equal(db_big.view(reps, 5, 128, 98), db_small.unsqueeze(0).expand(reps, -1, -1, -1))
+    raster_big = fe.encode(big)
+    raster_small = fe.encode(base)
+    assert torch.equal(raster_big.view(reps, 5, 128, 400), raster_small.unsqueeze(0).expand(reps, -1, -1, -1))
+
+
 def test_frontend_against_numpy_scipy_restatement(torch_cuda):
     """Same path against the literal NumPy/SciPy restatement (scipy.signal.lfilter inside)."""
     from lsm_speech_classifier_amd import frontend
