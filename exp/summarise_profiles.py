@@ -18,9 +18,9 @@ PRODUCT = ("gammatone_kernel", "spec_to_spikes_kernel", "lif_dense_kernel", "lif
 
 def one(pattern):
     hits = glob.glob(os.path.join(SRC, pattern))
-    if len(hits) != 1:
-        raise SystemExit(f"expected one file for {pattern}, found {hits}")
-    return hits[0]
+    if not hits:
+        raise SystemExit(f"no file for {pattern}")
+    return max(hits, key=os.path.getmtime)      # gpurun merges into the local copy: take the newest run
 
 
 def last_json_line(path):
