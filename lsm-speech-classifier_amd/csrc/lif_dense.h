@@ -124,8 +124,11 @@ __global__ __launch_bounds__(WPC * 64) void lif_dense_kernel(const DenseArgs a)
     const float theta = a.theta, w_in = a.w_in;
     const uint32_t *my_ent = a.in_ent + (size_t)w * a.EinW;
     const bool trace = a.spike_matrix != nullptr || a.v_trace != nullptr;
-    const float *wt_mine = a.wt + (size_t)(w * NPW) + lane;     // + j*ld + r*64: weight j -> my target
-    const size_t ld = (size_t)a.ld;
+    // weight of presynaptic j onto my target r: byte offset j*ld*4 (scalar, 32 bits are enough:
+    // N*ld*4 <= 2^28 for N <= 8192) + my lane's byte offset (vector) + r*256 (immediate)
+    const char *wt_bytes = reinterpret_cast<const char *>(a.wt);
+    const uint32_t ld_bytes = (uint32_t)a.ld * 4u;
+    const uint32_t lane_off = (uint32_t)(w * NPW + lane) * 4u;
     __syncthreads();
 
     // input drive of step `ts`: count the active channels feeding each target (integer atomics)
@@ -171,33 +174,35 @@ __global__ __launch_bounds__(WPC * 64) void lif_dense_kernel(const DenseArgs a)
             if (LSM_ABLATE & 1) todo = 0ull;
             if (LSM_ABLATE & 4) jl = min(jl, (uint32_t)(N - 1));
             while (todo != 0ull) {
-                const int n8 = min((int)__popcll(todo), G);
+                const int n8 = min((int)__builtin_popcountll(todo), G);
                 float wv[16][SL];                   // only the first G rows are ever live
 #define LSM_LD(k)                                                                   \
     {                                                                               \
         const int sk = __builtin_ctzll(todo);                                       \
         todo &= todo - 1ull;                                                        \
         const uint32_t j = __builtin_amdgcn_readlane(jl, sk);                       \
-        const float *rowp = wt_mine + (size_t)((LSM_ABLATE & 32) ? (j & 255u) : j) * ld; \
+        const char *rowp = wt_bytes + (((LSM_ABLATE & 32) ? (j & 255u) : j) * ld_bytes); \
         _Pragma("unroll") for (int r = 0; r < SL; ++r)                              \
-            wv[k][r] = (LSM_ABLATE & 16) ? __uint_as_float(j + r) : rowp[r * 64];   \
+            wv[k][r] = (LSM_ABLATE & 16) ? __uint_as_float(j + r)                   \
+                     : *reinterpret_cast<const float *>(rowp + lane_off + r * 256); \
     }
+                // the load chain tests the remaining-entries mask itself (one scalar 64-bit compare per row)
                 LSM_LD(0)
-                if (n8 > 1) { LSM_LD(1)
-                if (n8 > 2) { LSM_LD(2)
-                if (n8 > 3) { LSM_LD(3)
-                if (n8 > 4) { LSM_LD(4)
-                if (n8 > 5) { LSM_LD(5)
-                if (n8 > 6) { LSM_LD(6)
-                if (n8 > 7) { LSM_LD(7)
-                if (n8 > 8) { LSM_LD(8)
-                if (n8 > 9) { LSM_LD(9)
-                if (n8 > 10) { LSM_LD(10)
-                if (n8 > 11) { LSM_LD(11)
-                if (n8 > 12) { LSM_LD(12)
-                if (n8 > 13) { LSM_LD(13)
-                if (n8 > 14) { LSM_LD(14)
-                if (n8 > 15) { LSM_LD(15) } } } } } } } } } } } } } } }
+                if (G > 1 && todo) { LSM_LD(1)
+                if (G > 2 && todo) { LSM_LD(2)
+                if (G > 3 && todo) { LSM_LD(3)
+                if (G > 4 && todo) { LSM_LD(4)
+                if (G > 5 && todo) { LSM_LD(5)
+                if (G > 6 && todo) { LSM_LD(6)
+                if (G > 7 && todo) { LSM_LD(7)
+                if (G > 8 && todo) { LSM_LD(8)
+                if (G > 9 && todo) { LSM_LD(9)
+                if (G > 10 && todo) { LSM_LD(10)
+                if (G > 11 && todo) { LSM_LD(11)
+                if (G > 12 && todo) { LSM_LD(12)
+                if (G > 13 && todo) { LSM_LD(13)
+                if (G > 14 && todo) { LSM_LD(14)
+                if (G > 15 && todo) { LSM_LD(15) } } } } } } } } } } } } } } }
 #undef LSM_LD
                 if (!drove) {                     // the input counts fill the load latency
                     input_drive(t);
