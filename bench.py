@@ -24,9 +24,10 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 # The steps rotate over several HIP streams; the runtime multiplexes streams onto 4 hardware queues by
-# default and kernels of streams that share a queue serialise.  Eight queues let six streams overlap
-# (measured at cfg2: 0.96 -> 0.82 ms per step; exp/hwq_sweep.sh).  Must be set before HIP initialises.
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+# default and kernels of streams that share a queue serialise.  With 8 or more queues six streams overlap
+# (measured at cfg2: 0.96 -> 0.82 ms per step; exp/hwq_sweep.sh); 12 also leave RCCL's stream a queue of
+# its own when N > 1 (exp/dist_rehearsal.sh).  Must be set before HIP initialises.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "12")
 
 import numpy as np
 import torch
@@ -205,7 +206,7 @@ def main():
             if use_dist:
                 step_no[0] += 1
                 gathered = gather_bufs[step_no[0] % n_streams]
-                dist.all_gather_into_tensor(gathered, feats)
+                gather(gathered, feats)
                 return gathered
             return feats
 
@@ -225,9 +226,15 @@ def main():
             ev_pairs.append((e0, e1))
         if use_dist:
             gathered = gather_bufs[(step_no[0] - 1) % n_streams]
-            dist.all_gather_into_tensor(gathered, feats)
+            gather(gathered, feats)
             return gathered
         return feats
+
+    def gather(dst, src):
+        # RCCL's stream is ordered after this step's reservoir kernel and the step's stream after the
+        # gather; with >= 12 hardware queues the exchange does not disturb the other steps in flight
+        # (single-rank rehearsal: 0.785 ms per step with the gather, 0.77 without; exp/dist_rehearsal.sh)
+        dist.all_gather_into_tensor(dst, src)
 
     def fence():
         torch.cuda.synchronize()
