@@ -128,3 +128,30 @@ def test_lif_properties(seed, refr, dens, mult):
     f = feats.reshape(8, n)
     np.testing.assert_array_equal(f[0], counts)
     assert np.all(f[3] <= f[4]) and np.all(f[7] <= np.maximum(counts - 1, 0))
+
+
+def test_float64_twin_drift_is_below_the_north_star_tolerance():
+    """the float64 twin of the LIF loop.  In the sub-critical regime the pipeline
+    runs in (multiplier 0.6) rounding does not move the trajectory: the float32 membrane trace stays
+    within 1e-5 relative of the float64 one for as long as the spike rasters agree, and the rasters
+    agree (almost) everywhere.  This is a measurement of the SPEC, not a parity gate: the GPU is
+    compared bit for bit with the float32 oracle."""
+    from lsm_speech_classifier_amd import reservoir as R, synth
+    rasters = synth.bernoulli_raster(3, 64, 400, 0.2, seed=21)
+    wc = O.w_critico(100, 2.0, 2, rasters)
+    p = R.SimulationParams(num_neurons=500, num_output_neurons=200, small_world_graph_k=100,
+                           mean_weight=wc * 0.6)
+    res = R.build_reservoir(p, 64)
+    for r in rasters:
+        d = O.lif_drift(res, r)
+        assert d["spikes_fp32"] > 100
+        assert d["max_rel_membrane_diff_before"] <= 1e-5, d
+        assert d["spike_bit_mismatch_share"] <= 1e-3, d
+    # the twin really computes in float64: on a tiny case its trace differs from float32 in the last bits
+    tiny = _tiny(2, [(0, 1, 0.1)], leak=0.1, theta=10.0, in_map=[(0, 0), (0, 1)], w_in=0.3)
+    x = np.ones((1, 8), dtype=np.uint8)
+    _, v32 = O.lif_run(tiny, x, want_trace=True)
+    _, v64 = O.lif_run(tiny, x, want_trace=True, dtype=np.float64)
+    assert v64.dtype == np.float64 and v32.dtype == np.float32
+    assert np.any(v32.astype(np.float64) != v64)
+    np.testing.assert_allclose(v32, v64, rtol=1e-6)
