@@ -183,7 +183,10 @@ __global__ __launch_bounds__(256) void spec_to_spikes_kernel(const SpikeArgs<T> 
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     T *scratch = reinterpret_cast<T *>(smem);                 // 8 entries
-    uint8_t *stage = smem + 64;                               // F * time_bins * n_thr bytes
+    // the clip's raster is staged bit-packed (F rows of RW words; bit p of a row = raster byte p), so the
+    // kernel needs 6.7 KB of LDS at 128 filters instead of 51 KB and fits beside the workgroups of the
+    // other kernels of the pipeline
+    uint32_t *stage = reinterpret_cast<uint32_t *>(smem + 64);
     const int b = blockIdx.x;
     const int F = a.n_filters, nc = a.ncols, Tb = a.time_bins;
     const T *db = a.db + (size_t)b * F * nc;
@@ -204,6 +207,7 @@ __global__ __launch_bounds__(256) void spec_to_spikes_kernel(const SpikeArgs<T> 
     const bool flat = (hi - lo) < (T)1e-8;
     const T den = (hi - lo) + (T)1e-8;
     const int row_bytes = Tb * a.n_thr;
+    const int RW = (row_bytes + 31) >> 5;                     // words per staged row
     const double zf = (double)(nc - 1) / (double)(Tb - 1);
 
     for (int r = threadIdx.x; r < F; r += blockDim.x) {
@@ -211,6 +215,8 @@ __global__ __launch_bounds__(256) void spec_to_spikes_kernel(const SpikeArgs<T> 
         bool active[MAX_THR];
 #pragma unroll
         for (int q = 0; q < MAX_THR; ++q) active[q] = false;
+        uint32_t word = 0u;
+        int pos = 0;                                          // bit position in the row = j*n_thr + q
         for (int j = 0; j < Tb; ++j) {
             T val;
             if (flat) {
@@ -246,10 +252,16 @@ __global__ __launch_bounds__(256) void spec_to_spikes_kernel(const SpikeArgs<T> 
                     const bool falling = (val < a.off[q]) && active[q];
                     if (rising) active[q] = true;
                     if (falling) active[q] = false;
-                    stage[(size_t)r * row_bytes + j * a.n_thr + q] = active[q] ? 1 : 0;
+                    word |= (active[q] ? 1u : 0u) << (pos & 31);
+                    if ((pos & 31) == 31) {
+                        stage[r * RW + (pos >> 5)] = word;
+                        word = 0u;
+                    }
+                    ++pos;
                 }
             }
         }
+        if (pos & 31) stage[r * RW + (pos >> 5)] = word;
     }
     __syncthreads();
     if (a.raster) {
@@ -257,17 +269,21 @@ __global__ __launch_bounds__(256) void spec_to_spikes_kernel(const SpikeArgs<T> 
         const int C = F * a.redundancy;
         uint8_t *dst = a.raster + (size_t)b * C * row_bytes;
         if ((row_bytes & 3) == 0) {
+            // four raster bytes per store: bits p..p+3 (p a multiple of 4, so they share a word)
+            // spread to one bit per byte by a multiply
             const int rw = row_bytes / 4;
-            const uint32_t *s4 = reinterpret_cast<const uint32_t *>(stage);
             uint32_t *d4 = reinterpret_cast<uint32_t *>(dst);
             for (int i = threadIdx.x; i < C * rw; i += blockDim.x) {
                 const int c = i / rw;
-                d4[i] = s4[(c / a.redundancy) * rw + (i - c * rw)];
+                const int p = (i - c * rw) * 4;
+                const uint32_t nib = (stage[(c / a.redundancy) * RW + (p >> 5)] >> (p & 31)) & 0xFu;
+                d4[i] = (nib * 0x00204081u) & 0x01010101u;
             }
         } else {
             for (int i = threadIdx.x; i < C * row_bytes; i += blockDim.x) {
                 const int c = i / row_bytes;
-                dst[i] = stage[(size_t)(c / a.redundancy) * row_bytes + (i - c * row_bytes)];
+                const int p = i - c * row_bytes;
+                dst[i] = (uint8_t)((stage[(c / a.redundancy) * RW + (p >> 5)] >> (p & 31)) & 1u);
             }
         }
     }
@@ -318,7 +334,7 @@ int launch_spec_to_spikes(const T *db, int n_clips, int n_filters, int ncols, in
     a.time_bins = time_bins; a.apply_floor = apply_floor; a.n_thr = n_thr;
     a.redundancy = redundancy; a.raster = raster; a.norm_out = norm_out;
     for (int q = 0; q < MAX_THR; ++q) { a.on[q] = q < n_thr ? thr_on[q] : (T)0; a.off[q] = q < n_thr ? thr_off[q] : (T)0; }
-    const size_t lds = 64 + (size_t)n_filters * time_bins * (n_thr > 0 ? n_thr : 1);
+    const size_t lds = 64 + (size_t)n_filters * (((size_t)time_bins * n_thr + 31) / 32) * 4;
     LSM_REQUIRE(lds <= 160 * 1024, "raster stage of %zu bytes exceeds one CU's LDS", lds);
     auto fn = spec_to_spikes_kernel<T>;
     if (lds > 64 * 1024)
