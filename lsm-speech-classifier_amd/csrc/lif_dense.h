@@ -37,6 +37,7 @@ struct DenseArgs {
     const float *leak;         // (NPAD)
     const int *oslot;          // (NPAD) output slot or -1
     const uint32_t *in_ent;    // (WPC, EinW) (channel << 16) | target, 0xFFFFFFFF = padding
+    const uint32_t *inmask;    // (NPAD, 4) input-channel bit mask per neuron (INMODE 2: C <= 128), or null
     int n_keys;
     int key_ids[8];
     float *features;           // (B, n_keys * n_out)
@@ -44,9 +45,17 @@ struct DenseArgs {
     float *v_trace;            // (B, T, N) or null
 };
 
-template <int SL, int WPC, bool INREG>
+// INMODE: how the input drive m_i(t) = #{active channels feeding neuron i} is formed.
+//   0  the wave's (channel, target) entries are streamed from global memory, integer LDS atomics count
+//   1  the entries sit in registers (<= IN_REG_SLOTS*64 per wave), integer LDS atomics count
+//   2  every neuron holds the bit mask of its input channels in registers (C <= 128, SL <= 4) and counts
+//      popcount(mask & row) against the step's wave-uniform input bit row: no atomics, no count array,
+//      and nothing to wait for between the recurrent rows and the update
+template <int SL, int WPC, int INMODE>
 __global__ __launch_bounds__(WPC * 64) void lif_dense_kernel(const DenseArgs a)
 {
+    constexpr bool INREG = INMODE == 1;
+    constexpr bool INMASK = INMODE == 2;
     constexpr int NPW = SL * 64;
     constexpr int NPAD = NPW * WPC;
     constexpr int NT = WPC * 64;
@@ -108,6 +117,14 @@ __global__ __launch_bounds__(WPC * 64) void lif_dense_kernel(const DenseArgs a)
         lam[r] = a.leak[i];
         os[r] = a.oslot[i];
     }
+    uint32_t im[SL][4];                 // INMASK: channels 0..127 feeding my neuron r
+    if (INMASK) {
+#pragma unroll
+        for (int r = 0; r < SL; ++r) {
+            const uint4 m = reinterpret_cast<const uint4 *>(a.inmask)[(w * SL + r) * 64 + lane];
+            im[r][0] = m.x; im[r][1] = m.y; im[r][2] = m.z; im[r][3] = m.w;
+        }
+    }
     uint32_t in_word[IN_REG_SLOTS], in_mask[IN_REG_SLOTS], in_tgt[IN_REG_SLOTS];
     if (INREG) {
 #pragma unroll
@@ -133,7 +150,7 @@ __global__ __launch_bounds__(WPC * 64) void lif_dense_kernel(const DenseArgs a)
 
     // input drive of step `ts`: count the active channels feeding each target (integer atomics)
     auto input_drive = [&](int ts) {
-        if (LSM_ABLATE & 2) return;
+        if (INMASK || (LSM_ABLATE & 2)) return;
         const uint32_t *row = bits + ts * CW;
         if (INREG) {
 #pragma unroll
@@ -166,6 +183,16 @@ __global__ __launch_bounds__(WPC * 64) void lif_dense_kernel(const DenseArgs a)
         float cin[SL];
 #pragma unroll
         for (int r = 0; r < SL; ++r) cin[r] = 0.0f;
+        uint32_t rowbits[4] = {0u, 0u, 0u, 0u};          // INMASK: this step's input bit row (wave-uniform)
+        if (INMASK && !(LSM_ABLATE & 2)) {
+            if (CW == 4) {
+                const uint4 q4 = *reinterpret_cast<const uint4 *>(bits + t * 4);
+                rowbits[0] = q4.x; rowbits[1] = q4.y; rowbits[2] = q4.z; rowbits[3] = q4.w;
+            } else {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) rowbits[q] = q < CW ? bits[t * CW + q] : 0u;
+            }
+        }
 
         // `todo`: filled entries of the step list; lane l holds entry l's neuron in `jl`.  Up to 8 rows
         // (G = 16/SL) are in flight; nested "one more?" tests make a group cost one taken branch.
@@ -259,7 +286,7 @@ __global__ __launch_bounds__(WPC * 64) void lif_dense_kernel(const DenseArgs a)
             }
         }
         if (!drove) input_drive(t);
-        wave_lds_fence();
+        if (!INMASK) wave_lds_fence();
 
         // ---- neuron update ----
         unsigned long long bal[SL];
@@ -267,8 +294,14 @@ __global__ __launch_bounds__(WPC * 64) void lif_dense_kernel(const DenseArgs a)
 #pragma unroll
         for (int r = 0; r < SL; ++r) {
             const int i = (w * SL + r) * 64 + lane;
-            const uint32_t nin = icnt[i];
-            icnt[i] = 0u;
+            uint32_t nin;
+            if (INMASK) {
+                nin = __popc(im[r][0] & rowbits[0]) + __popc(im[r][1] & rowbits[1]) +
+                      __popc(im[r][2] & rowbits[2]) + __popc(im[r][3] & rowbits[3]);
+            } else {
+                nin = icnt[i];
+                icnt[i] = 0u;
+            }
             cin[r] = cin[r] + w_in * (float)nin;         // SPEC.md §3: input term after the recurrent sum
             const bool held = ref[r] > 0;
             const float m = lam[r] * v[r];
@@ -357,33 +390,34 @@ __global__ __launch_bounds__(WPC * 64) void lif_dense_kernel(const DenseArgs a)
 
 typedef void (*dense_fn_t)(const DenseArgs);
 
-template <int SL, bool INREG>
+template <int SL, int INMODE>
 dense_fn_t pick_dense_wpc(int wpc)
 {
     switch (wpc) {
-    case 1: return lif_dense_kernel<SL, 1, INREG>;
-    case 2: return lif_dense_kernel<SL, 2, INREG>;
-    case 4: return lif_dense_kernel<SL, 4, INREG>;
-    case 8: return lif_dense_kernel<SL, 8, INREG>;
-    case 16: return lif_dense_kernel<SL, 16, INREG>;
+    case 1: return lif_dense_kernel<SL, 1, INMODE>;
+    case 2: return lif_dense_kernel<SL, 2, INMODE>;
+    case 4: return lif_dense_kernel<SL, 4, INMODE>;
+    case 8: return lif_dense_kernel<SL, 8, INMODE>;
+    case 16: return lif_dense_kernel<SL, 16, INMODE>;
     default: return nullptr;
     }
 }
 
-template <bool INREG>
+template <int INMODE>
 dense_fn_t pick_dense_sl(int sl, int wpc)
 {
     switch (sl) {
-    case 1: return pick_dense_wpc<1, INREG>(wpc);
-    case 2: return pick_dense_wpc<2, INREG>(wpc);
-    case 4: return pick_dense_wpc<4, INREG>(wpc);
-    case 8: return pick_dense_wpc<8, INREG>(wpc);
-    case 16: return pick_dense_wpc<16, INREG>(wpc);
+    case 1: return pick_dense_wpc<1, INMODE>(wpc);
+    case 2: return pick_dense_wpc<2, INMODE>(wpc);
+    case 4: return pick_dense_wpc<4, INMODE>(wpc);
+    case 8: if (INMODE == 2) return nullptr; else return pick_dense_wpc<INMODE == 2 ? 4 : 8, INMODE>(wpc);
+    case 16: if (INMODE == 2) return nullptr; else return pick_dense_wpc<INMODE == 2 ? 4 : 16, INMODE>(wpc);
     default: return nullptr;
     }
 }
 
-dense_fn_t pick_dense_0(int sl, int wpc);      // lif_dense_0.hip (INREG = false)
-dense_fn_t pick_dense_1(int sl, int wpc);      // lif_dense_1.hip (INREG = true)
+dense_fn_t pick_dense_0(int sl, int wpc);      // lif_dense_0.hip (INMODE 0: entries from global memory)
+dense_fn_t pick_dense_1(int sl, int wpc);      // lif_dense_1.hip (INMODE 1: entries in registers)
+dense_fn_t pick_dense_2(int sl, int wpc);      // lif_dense_2.hip (INMODE 2: channel masks, C <= 128, SL <= 4)
 
 }  // namespace lsm_lif

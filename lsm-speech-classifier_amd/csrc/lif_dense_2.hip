@@ -1,0 +1,6 @@
+// Dense-row LIF kernel instantiations with INMODE 2: input-channel masks in registers (see lif_dense.h).
+#include "lif_dense.h"
+
+namespace lsm_lif {
+dense_fn_t pick_dense_2(int sl, int wpc) { return pick_dense_sl<2>(sl, wpc); }
+}  // namespace lsm_lif

@@ -42,6 +42,7 @@ struct Variant {            // per waves-per-clip layout
     float *leak = nullptr;
     int *oslot = nullptr;
     uint32_t *in_ent = nullptr;
+    uint32_t *inmask = nullptr;      // (npad, 4) input-channel masks, only when C <= 128 and sl <= 4
 };
 
 }  // namespace
@@ -71,6 +72,7 @@ static int free_reservoir(lsm_reservoir *h)
         if (v.leak) (void)hipFree(v.leak);
         if (v.oslot) (void)hipFree(v.oslot);
         if (v.in_ent) (void)hipFree(v.in_ent);
+        if (v.inmask) (void)hipFree(v.inmask);
     }
     delete h;
     return LSM_OK;
@@ -181,6 +183,23 @@ int lsm_reservoir_create(lsm_reservoir **out, int num_neurons, int n_channels,
             (rc = upload(&v.in_ent, ent))) {
             free_reservoir(h);
             return rc;
+        }
+        if (C <= 128 && sl <= 4) {
+            // INMODE 2 of the dense kernel: bit c of neuron i's mask = channel c feeds neuron i (each
+            // (channel, neuron) pair occurs at most once: SPEC.md 2.4 draws targets without replacement)
+            std::vector<uint32_t> im((size_t)npad * 4, 0u);
+            bool distinct = true;
+            for (int c = 0; c < C; ++c)
+                for (int d = 0; d < in_fanout; ++d) {
+                    const int tgt = in_tgt[(size_t)c * in_fanout + d];
+                    uint32_t &word = im[(size_t)tgt * 4 + (c >> 5)];
+                    distinct = distinct && !(word & (1u << (c & 31)));
+                    word |= 1u << (c & 31);
+                }
+            if (distinct && (rc = upload(&v.inmask, im))) {
+                free_reservoir(h);
+                return rc;
+            }
         }
         v.wpc = wpc; v.sl = sl; v.einw = einw;
     }
@@ -297,8 +316,9 @@ int lsm_reservoir_run(const lsm_reservoir *h, const uint8_t *spikes_u8, int n_cl
     for (int k = 0; k < n_keys; ++k)
         LSM_REQUIRE(key_ids[k] >= 0 && key_ids[k] < 8, "key id %d out of range", key_ids[k]);
     if (use_dense(h)) {
-        lsm_lif::dense_fn_t dfn = lif_inreg(*v) ? lsm_lif::pick_dense_1(v->sl, v->wpc)
-                                                : lsm_lif::pick_dense_0(v->sl, v->wpc);
+        lsm_lif::dense_fn_t dfn = v->inmask       ? lsm_lif::pick_dense_2(v->sl, v->wpc)
+                                  : lif_inreg(*v) ? lsm_lif::pick_dense_1(v->sl, v->wpc)
+                                                  : lsm_lif::pick_dense_0(v->sl, v->wpc);
         LSM_REQUIRE(dfn != nullptr, "no dense kernel for SL=%d WPC=%d", v->sl, v->wpc);
         lsm_lif::DenseArgs d;
         d.N = h->N; d.C = h->C; d.T = n_steps; d.B = n_clips;
@@ -306,6 +326,7 @@ int lsm_reservoir_run(const lsm_reservoir *h, const uint8_t *spikes_u8, int n_cl
         d.refractory = h->refractory; d.burst_isi_max = h->burst_isi_max; d.ld = h->ld;
         d.theta = h->theta; d.w_in = h->w_in;
         d.raster = spikes_u8; d.wt = h->wt; d.leak = v->leak; d.oslot = v->oslot; d.in_ent = v->in_ent;
+        d.inmask = v->inmask;
         d.n_keys = n_keys;
         for (int k = 0; k < 8; ++k) d.key_ids[k] = k < n_keys ? key_ids[k] : 0;
         d.features = features_out; d.spike_matrix = spike_matrix_out; d.v_trace = v_trace_out;
