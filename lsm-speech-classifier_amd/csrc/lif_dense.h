@@ -16,8 +16,8 @@
 // Spike exchange: each producer wave writes its spiking neurons (ballot + mbcnt ranks, ascending) into its
 // own LDS list; the first R = 64/WPC also go to the wave's fixed region of a 64-entry step list, so lane l of
 // a consumer knows its entry (l) and whether it is filled (l%R < count of producer l/R) without any merge;
-// a producer with more than R spikes raises a (triple-buffered) overflow word and the consumers merge the
-// per-wave lists for that step (scalar prefix over the counts + compare chain).
+// when a producer has more than R spikes (its count says so) the consumers merge the per-wave lists for that
+// step instead (scalar prefix over the counts + compare chain).
 #pragma once
 #include "lif_kernel.h"
 
@@ -65,7 +65,7 @@ __global__ __launch_bounds__(WPC * 64) void lif_dense_kernel(const DenseArgs a)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint32_t *icnt = reinterpret_cast<uint32_t *>(smem);                              // NPAD
     uint16_t *wlist = reinterpret_cast<uint16_t *>(icnt + NPAD);                      // 2*NPAD
-    uint32_t *wcnt = reinterpret_cast<uint32_t *>(wlist + 2 * NPAD);                  // 2*16 counts, 3 overflow words
+    uint32_t *wcnt = reinterpret_cast<uint32_t *>(wlist + 2 * NPAD);                  // 2*16 counts
     uint16_t *flist = reinterpret_cast<uint16_t *>(wcnt + 64);                        // 2*64 fixed-region list
     uint4 *feat = reinterpret_cast<uint4 *>(wcnt + 128);                              // n_out
     uint32_t *bits = reinterpret_cast<uint32_t *>(feat + a.n_out);                    // T*CW
@@ -176,9 +176,6 @@ __global__ __launch_bounds__(WPC * 64) void lif_dense_kernel(const DenseArgs a)
         const int cur = t & 1, prv = cur ^ 1;
         const uint16_t *list_prev = wlist + prv * NPAD;
         uint16_t *list_cur = wlist + cur * NPAD + w * NPW;
-        // overflow words are triple-buffered by t mod 3: producers of step t set word t%3, consumers of
-        // step t+1 read it, it is cleared during step t+2 -- three steps, each separated by the barrier
-        const int f_set = t % 3, f_read = (t + 2) % 3, f_clear = (t + 1) % 3;
 
         float cin[SL];
 #pragma unroll
@@ -259,9 +256,8 @@ __global__ __launch_bounds__(WPC * 64) void lif_dense_kernel(const DenseArgs a)
         // ---- spiking neurons of step t-1 ----
         const uint32_t pcnt = wcnt[prv * 16 + lane / R];            // spikes of producer wave lane/R
         const uint32_t jfix = flist[prv * 64 + lane];               // its (lane%R)-th spiking neuron
-        const uint32_t overflow = wcnt[32 + f_read];
-        if (tid == 0) wcnt[32 + f_clear] = 0u;
-        if (__builtin_amdgcn_readfirstlane(overflow) == 0u) {
+        // a producer with more than R spikes does not fit its fixed region: the counts themselves say so
+        if (__ballot(pcnt > (uint32_t)R) == 0ull) {
             add_rows(__ballot((uint32_t)(lane % R) < pcnt), jfix);
         } else {
             // general path: merge the per-wave lists (scalar prefix over the counts, compare chain)
@@ -342,10 +338,7 @@ __global__ __launch_bounds__(WPC * 64) void lif_dense_kernel(const DenseArgs a)
                 nspk += __popcll(bal[r]);
             }
         }
-        if (lane == 0) {
-            wcnt[cur * 16 + w] = (uint32_t)nspk;
-            if (nspk > R) wcnt[32 + f_set] = 1u;         // next step's consumers take the general path
-        }
+        if (lane == 0) wcnt[cur * 16 + w] = (uint32_t)nspk;   // > R: next step's consumers merge the lists
         if (trace) {
 #pragma unroll
             for (int r = 0; r < SL; ++r) {
