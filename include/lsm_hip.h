@@ -95,7 +95,8 @@ int lsm_encode_hysteresis_f32(const float *spec, int n_rows, int n_bins, const f
  * array written by /root/reference/create_dataset.py:168-176, 8x smaller on disk and over PCIe).
  * raster (n_rows, n_steps) uint8, any non-zero byte is a spike; packed (n_rows, ceil(n_steps/8)) uint8,
  * time step 8q+k of a row in bit k of its byte q (numpy.packbits(..., bitorder="little")), unused
- * high bits of the last byte zero.  Unpacking writes 0/1 bytes.  Both buffers 8-byte aligned. */
+ * high bits of the last byte zero.  Unpacking writes 0/1 bytes.  The raster must be 8-byte aligned when
+ * n_steps is a multiple of 8 (it then moves as 64-bit words). */
 int lsm_raster_pack_bits(const uint8_t *raster, long n_rows, int n_steps, uint8_t *packed, void *stream);
 int lsm_raster_unpack_bits(const uint8_t *packed, long n_rows, int n_steps, uint8_t *raster, void *stream);
 

@@ -540,12 +540,15 @@ LSM_API int lsm_encode_hysteresis_f32(const float *spec, int n_rows, int n_bins,
     return launch_encode<float>(spec, n_rows, n_bins, thr_on, thr_off, n_thr, out, stream);
 }
 
-static int check_bits_args(const void *a, const void *b, long n_rows, int T, const char *what)
+static int check_bits_args(const void *a, const void *b, const void *raster, long n_rows, int T,
+                           const char *what)
 {
     LSM_REQUIRE(n_rows >= 0 && T >= 1, "%s: bad shape", what);
     if (n_rows == 0) return 1;
     LSM_REQUIRE(a && b, "%s: null buffer", what);
-    LSM_REQUIRE(((uintptr_t)a & 7u) == 0 && ((uintptr_t)b & 7u) == 0, "%s: buffers must be 8-byte aligned", what);
+    // rows of a multiple of 8 steps move as 64-bit words; other lengths go byte by byte
+    LSM_REQUIRE((T & 7) != 0 || ((uintptr_t)raster & 7u) == 0,
+                "%s: the raster must be 8-byte aligned when n_steps is a multiple of 8", what);
     LSM_REQUIRE(n_rows * (long)((T + 7) / 8) <= 0x7fffffffL * 256L, "%s: too many rows", what);
     return LSM_OK;
 }
@@ -553,7 +556,7 @@ static int check_bits_args(const void *a, const void *b, long n_rows, int T, con
 LSM_API int lsm_raster_pack_bits(const uint8_t *raster, long n_rows, int n_steps, uint8_t *packed,
                                  void *stream)
 {
-    const int rc = check_bits_args(raster, packed, n_rows, n_steps, "pack_bits");
+    const int rc = check_bits_args(raster, packed, raster, n_rows, n_steps, "pack_bits");
     if (rc != LSM_OK) return rc == 1 ? LSM_OK : rc;
     const int TP = (n_steps + 7) / 8;
     const long n = n_rows * TP;
@@ -566,7 +569,7 @@ LSM_API int lsm_raster_pack_bits(const uint8_t *raster, long n_rows, int n_steps
 LSM_API int lsm_raster_unpack_bits(const uint8_t *packed, long n_rows, int n_steps, uint8_t *raster,
                                    void *stream)
 {
-    const int rc = check_bits_args(packed, raster, n_rows, n_steps, "unpack_bits");
+    const int rc = check_bits_args(packed, raster, raster, n_rows, n_steps, "unpack_bits");
     if (rc != LSM_OK) return rc == 1 ? LSM_OK : rc;
     const int TP = (n_steps + 7) / 8;
     const long n = n_rows * TP;
