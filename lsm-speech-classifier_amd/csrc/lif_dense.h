@@ -191,8 +191,8 @@ __global__ __launch_bounds__(WPC * 64) void lif_dense_kernel(const DenseArgs a)
             }
         }
 
-        // `todo`: filled entries of the step list; lane l holds entry l's neuron in `jl`.  Up to 8 rows
-        // (G = 16/SL) are in flight; nested "one more?" tests make a group cost one taken branch.
+        // `todo`: filled entries of the step list; lane l holds entry l's neuron in `jl`.  Up to G rows
+        // are in flight; nested "one more?" tests make a group cost one taken branch.
         bool drove = false;
         auto add_rows = [&](unsigned long long todo, uint32_t jl) {
             if (LSM_ABLATE & 1) todo = 0ull;

@@ -204,7 +204,7 @@ int lsm_reservoir_create(lsm_reservoir **out, int num_neurons, int n_channels,
         v.wpc = wpc; v.sl = sl; v.einw = einw;
     }
     // dense presynaptic rows for the register-accumulating kernel (lif_dense.h): N x ld floats, only
-    // while that stays small enough for L2 / Infinity Cache (N <= 2048: <= 16 MB)
+    // up to N = 8192 (4 MB at N = 1000: L2; 64 MB at N = 4000 and 262 MB at N = 8000: Infinity Cache / HBM)
     if (N <= 8192) {
         int ldmax = 0;
         for (const auto &v : h->var)
