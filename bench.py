@@ -344,6 +344,10 @@ def main():
                 "kernels": "gammatone_kernel + spec_to_spikes_kernel", "idle_gpu_ms": round(fe_ms, 4),
                 "bound": "valu_f64", "achieved_tflops": round(ops / (fe_ms * 1e-3) / 1e12, 2),
                 "peak_tflops_fma_counted": 78.6, "peak_tops_unfused": 39.3,
+                # the same instruction count over the measured step time of the whole (overlapped) pipeline:
+                # how much of the chip's f64 issue rate the benchmark as a whole sustains
+                "pipeline_tops": round(ops / (ms_step * 1e-3) / 1e12, 2),
+                "pipeline_frac_of_unfused_peak": round(ops / (ms_step * 1e-3) / 1e12 / 39.3, 4),
                 "note": "one float64 operation per lane and instruction (no FMA contraction allowed): the "
                         "ceiling for this instruction mix is 39.3 Tops/s with all 1024 SIMDs busy and >= 4 "
                         f"waves per SIMD (exp/ubench_f64.hip); this launch has {gt_waves} waves",
