@@ -58,6 +58,20 @@ def test_bad_arguments_raise_and_library_survives():
         snn.SNN(None, reservoir=bad)
     with pytest.raises(_lib.LsmHipError, match="membrane_threshold"):
         snn.SNN(R.SimulationParams(num_neurons=100, small_world_graph_k=10, membrane_threshold=0.0), n_channels=8)
+    # bit packing: bad shape, null buffer, misaligned raster for rows that move as 64-bit words
+    ras = torch.zeros((4, 16), dtype=torch.uint8, device="cuda")
+    pk = torch.zeros((4, 2), dtype=torch.uint8, device="cuda")
+    for fn, a, b in ((lib.lsm_raster_pack_bits, ras, pk), (lib.lsm_raster_unpack_bits, pk, ras)):
+        assert fn(p(a), 4, 0, p(b), stream) < 0 and b"bad shape" in lib.lsm_last_error()
+        assert fn(p(a), -1, 16, p(b), stream) < 0
+        assert fn(None, 4, 16, p(b), stream) < 0 and b"null" in lib.lsm_last_error()
+        assert fn(p(a), 0, 16, None, stream) == 0            # nothing to do: no buffers needed
+    odd = torch.zeros(4 * 16 + 1, dtype=torch.uint8, device="cuda")[1:].view(4, 16)
+    assert lib.lsm_raster_pack_bits(p(odd), 4, 16, p(pk), stream) < 0 and b"aligned" in lib.lsm_last_error()
+    odd15 = torch.zeros(4 * 15 + 1, dtype=torch.uint8, device="cuda")[1:].view(4, 15)
+    assert lib.lsm_raster_pack_bits(p(odd15), 4, 15, p(pk), stream) == 0      # byte path: any alignment
+    with pytest.raises(ValueError):                       # packed width does not match the step count
+        net.run_batch(np.zeros((1, 8, 5), dtype=np.uint8), packed_time_steps=400)
     # ... and the library still works
     f, _, _ = net.run_batch(rasters)
     assert f.shape == (2, 8 * 40) and torch.isfinite(f).all()
