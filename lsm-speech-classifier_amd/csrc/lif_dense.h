@@ -172,6 +172,9 @@ __global__ __launch_bounds__(WPC * 64) void lif_dense_kernel(const DenseArgs a)
         }
     };
 
+#ifdef LSM_LIF_PRIO
+    __builtin_amdgcn_s_setprio(LSM_LIF_PRIO);
+#endif
     for (int t = 0; t < T; ++t) {
         const int cur = t & 1, prv = cur ^ 1;
         const uint16_t *list_prev = wlist + prv * NPAD;
