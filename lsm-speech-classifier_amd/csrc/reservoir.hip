@@ -274,9 +274,13 @@ static size_t dense_lds_bytes(const lsm_reservoir *h, const Variant &v, int T)
 // supports and whose LDS image fits one CU, take the smallest one at or above that target.
 static const Variant *choose_variant(const lsm_reservoir *h, int B, int T, int requested)
 {
+    // LDS image of the kernel that will run (the dense-row kernel needs less than the sparse one)
+    auto lds_of = [&](const Variant &v) {
+        return use_dense(h) ? dense_lds_bytes(h, v, T) : lif_lds_bytes(h, v, T);
+    };
     if (requested > 0) {
         for (const auto &v : h->var)
-            if (v.wpc == requested && lif_lds_bytes(h, v, T) <= 160 * 1024) return &v;
+            if (v.wpc == requested && lds_of(v) <= 160 * 1024) return &v;
         return nullptr;
     }
     int target = 4;
@@ -288,7 +292,7 @@ static const Variant *choose_variant(const lsm_reservoir *h, int B, int T, int r
     // wave) small -- N=4000, B=1024: 4 waves 68 ms, 8 waves 43 ms, 16 waves 26 ms
     const Variant *best = nullptr;
     for (const auto &v : h->var) {
-        if (!v.wpc || lif_lds_bytes(h, v, T) > 160 * 1024) continue;
+        if (!v.wpc || lds_of(v) > 160 * 1024) continue;
         if (!best || best->wpc < target || best->sl > 4) best = &v;
     }
     return best;
