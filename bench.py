@@ -251,6 +251,7 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         out = step(True)
+    host_enqueue_ms = (time.perf_counter() - t0) / args.steps * 1e3      # host side of a step (asynchronous)
     fence()
     elapsed = time.perf_counter() - t0
     if use_dist:
@@ -305,6 +306,7 @@ def main():
                        "small_world_k": cfg["k"], "num_output_neurons": cfg["n_out"],
                        "time_steps": fe.n_steps, "feature_set": "original",
                        "waves_per_clip": lay["waves_per_clip"], "lds_bytes_per_clip": lay["lds_bytes"],
+                       "host_enqueue_ms_per_step": round(host_enqueue_ms, 4),
                        "streams": n_streams, "hw_queues": int(os.environ["GPU_MAX_HW_QUEUES"]),
                        "pipeline": args.pipeline if n_streams > 1 else "serial",
                        "mean_output_spikes_per_clip": spikes_per_clip,
