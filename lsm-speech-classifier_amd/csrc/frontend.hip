@@ -46,9 +46,6 @@ __global__ __launch_bounds__(GT_MAX_WPB * 64) void gammatone_kernel(
     // group) pairs.  A workgroup of 4 waves occupies each SIMD of its CU once: single-wave workgroups
     // are packed by the dispatcher up to the occupancy limit of a CU before the next CU is used
     // (2048 of them ran on half the chip, 3.7 ms instead of 2.6 ms at 1024 clips).
-#ifdef LSM_GT_PRIO
-    __builtin_amdgcn_s_setprio(LSM_GT_PRIO);
-#endif
     const int groups = (n_filters + 63) >> 6;
     const int wid = __builtin_amdgcn_readfirstlane(
         (int)(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)));

@@ -172,10 +172,13 @@ __global__ __launch_bounds__(WPC * 64) void lif_dense_kernel(const DenseArgs a)
         }
     };
 
-#ifdef LSM_LIF_PRIO
-    __builtin_amdgcn_s_setprio(LSM_LIF_PRIO);
-#endif
     for (int t = 0; t < T; ++t) {
+        // The step list read and the row fetch are the latency-critical part of a step: they issue at
+        // raised priority so that waves of other kernels sharing the SIMD (the float64 filterbank in the
+        // pipeline) do not delay the loads; the update below runs at normal priority in their stall slots.
+        // Measured inside the pipeline: launch duration 1.31 -> 1.11 ms at unchanged throughput (raising
+        // the priority for the whole step gives 0.67 ms but costs 4 % of the pipeline's throughput).
+        __builtin_amdgcn_s_setprio(1);
         const int cur = t & 1, prv = cur ^ 1;
         const uint16_t *list_prev = wlist + prv * NPAD;
         uint16_t *list_cur = wlist + cur * NPAD + w * NPW;
@@ -287,6 +290,7 @@ __global__ __launch_bounds__(WPC * 64) void lif_dense_kernel(const DenseArgs a)
         if (!drove) input_drive(t);
         if (!INMASK) wave_lds_fence();
 
+        __builtin_amdgcn_s_setprio(0);
         // ---- neuron update ----
         unsigned long long bal[SL];
         unsigned long long any_fire = 0ull;
