@@ -178,7 +178,9 @@ __global__ __launch_bounds__(WPC * 64) void lif_dense_kernel(const DenseArgs a)
         // pipeline) do not delay the loads; the update below runs at normal priority in their stall slots.
         // Measured inside the pipeline: launch duration 1.31 -> 1.11 ms at unchanged throughput (raising
         // the priority for the whole step gives 0.67 ms but costs 4 % of the pipeline's throughput).
+#ifndef LSM_LIF_NO_PRIO                  // diagnostic builds: same-box A/B of the priority phases
         __builtin_amdgcn_s_setprio(1);
+#endif
         const int cur = t & 1, prv = cur ^ 1;
         const uint16_t *list_prev = wlist + prv * NPAD;
         uint16_t *list_cur = wlist + cur * NPAD + w * NPW;
@@ -290,7 +292,9 @@ __global__ __launch_bounds__(WPC * 64) void lif_dense_kernel(const DenseArgs a)
         if (!drove) input_drive(t);
         if (!INMASK) wave_lds_fence();
 
+#ifndef LSM_LIF_NO_PRIO
         __builtin_amdgcn_s_setprio(0);
+#endif
         // ---- neuron update ----
         unsigned long long bal[SL];
         unsigned long long any_fire = 0ull;
