@@ -15,7 +15,7 @@ void lsm_set_error(const char *fmt, ...)
 
 #define LSM_API extern "C" __attribute__((visibility("default")))
 
-LSM_API int lsm_version(void) { return 100; }   // 0.1.0
+LSM_API int lsm_version(void) { return 101; }   // 0.1.1: + lsm_raster_pack_bits / lsm_raster_unpack_bits
 
 LSM_API const char *lsm_last_error(void) { return g_err; }
 
