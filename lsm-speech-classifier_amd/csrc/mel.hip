@@ -5,62 +5,98 @@
 // 0.11 defaults: n_fft = win_length = 2048, periodic Hann, centred frames with zero padding,
 // power 2, Slaney mel basis; amin 1e-10, top_db 80).  librosa multiplies the float64 window into the
 // float32 frame, transforms in float64 and stores complex64; the kernel follows the same dtypes.
-// One workgroup = one frame: 2048-point radix-2 FFT in LDS (float64), |.|^2 in float32, then the
-// triangular mel filters (each thread one filter, sequential over its non-zero bins).
+// One workgroup = one frame: real-input FFT as 1024 complex points, five radix-4 passes in LDS (float64),
+// |.|^2 in float32, then the triangular mel filters (four lanes per filter).
 #include "lsm_common.h"
 
 namespace {
 
 constexpr int NFFT = 2048;
-constexpr int LOG2N = 11;
+constexpr int N2 = NFFT / 2;                 // the real frame is transformed as N2 complex points
 constexpr int NBINS = NFFT / 2 + 1;
 
+// W_2048^m for any m in [0, 2048) from the table of the first 1024 powers (W^(m+1024) = -W^m)
+__device__ __forceinline__ double2 tw2048(const double2 *__restrict__ t, int m)
+{
+    const double2 w = t[m & (N2 - 1)];
+    return (m & N2) ? make_double2(-w.x, -w.y) : w;
+}
+__device__ __forceinline__ double2 cmul(double2 a, double2 b)
+{
+    return make_double2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
+}
+
+// One workgroup = one frame.  The 2048 windowed real samples are packed as 1024 complex points
+// z[n] = x[2n] + i x[2n+1], transformed by five radix-4 Stockham passes (one butterfly per thread and
+// pass, ping-pong between two LDS buffers, natural order in and out), and unpacked to the 1025 bins of
+// the real transform: X[k] = E[k] - i W^k O[k], E/O = (Z[k] +- conj Z[N2-k]) / 2.  All in float64.
 __global__ __launch_bounds__(256) void mel_power_kernel(
     const float *__restrict__ audio, int n_samples, int hop, int n_frames,
-    const double *__restrict__ window, const double2 *__restrict__ twiddle,   // W^k, k < NFFT/2
+    const double *__restrict__ window, const double2 *__restrict__ twiddle,   // W_2048^k, k < 1024
     const float *__restrict__ basis, const int *__restrict__ lo, const int *__restrict__ hi,
     int n_mels, float *__restrict__ power_out)
 {
-    __shared__ double2 x[NFFT];                 // 32 KB
+    __shared__ double2 buf[2][N2];              // 2 x 16 KB
     __shared__ float pw[NBINS + 3];
     const int t = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
     const float *clip = audio + (size_t)b * n_samples;
     const int start = t * hop - NFFT / 2;       // centred frame, zero padding outside the clip
 
-    for (int n = tid; n < NFFT; n += 256) {
-        const int src = start + n;
-        const double v = (src >= 0 && src < n_samples) ? (double)clip[src] : 0.0;
-        const int r = (int)(__brev((unsigned)n) >> (32 - LOG2N));
-        x[r] = make_double2(window[n] * v, 0.0);
+    for (int n = tid; n < N2; n += 256) {
+        const int s0 = start + 2 * n, s1 = s0 + 1;
+        const double v0 = (s0 >= 0 && s0 < n_samples) ? (double)clip[s0] : 0.0;
+        const double v1 = (s1 >= 0 && s1 < n_samples) ? (double)clip[s1] : 0.0;
+        buf[0][n] = make_double2(window[2 * n] * v0, window[2 * n + 1] * v1);
     }
     __syncthreads();
-    for (int s = 1; s <= LOG2N; ++s) {
-        const int half = 1 << (s - 1);
-        const int tstep = (NFFT / 2) >> (s - 1);
-        for (int q = tid; q < NFFT / 2; q += 256) {
-            const int k = q & (half - 1);
-            const int i0 = ((q >> (s - 1)) << s) + k;
-            const int i1 = i0 + half;
-            const double2 w = twiddle[k * tstep];
-            const double2 a = x[i0], c = x[i1];
-            const double tr = c.x * w.x - c.y * w.y;
-            const double ti = c.x * w.y + c.y * w.x;
-            x[i0] = make_double2(a.x + tr, a.y + ti);
-            x[i1] = make_double2(a.x - tr, a.y - ti);
-        }
+    int cur = 0;
+#pragma unroll
+    for (int p = 1; p < N2; p <<= 2) {          // p = 1, 4, 16, 64, 256
+        const double2 *in = buf[cur];
+        double2 *out = buf[cur ^ 1];
+        const int k = tid & (p - 1);
+        const int j = ((tid - k) << 2) + k;
+        const int e = k * (512 / p);            // exponent of W_2048 for this butterfly's first twiddle
+        const double2 u0 = in[tid];
+        const double2 u1 = cmul(in[tid + 256], tw2048(twiddle, e));
+        const double2 u2 = cmul(in[tid + 512], tw2048(twiddle, 2 * e));
+        const double2 u3 = cmul(in[tid + 768], tw2048(twiddle, 3 * e));
+        const double2 a0 = make_double2(u0.x + u2.x, u0.y + u2.y);
+        const double2 a1 = make_double2(u0.x - u2.x, u0.y - u2.y);
+        const double2 a2 = make_double2(u1.x + u3.x, u1.y + u3.y);
+        const double2 a3 = make_double2(u1.y - u3.y, -(u1.x - u3.x));      // -i (u1 - u3)
+        out[j] = make_double2(a0.x + a2.x, a0.y + a2.y);
+        out[j + p] = make_double2(a1.x + a3.x, a1.y + a3.y);
+        out[j + 2 * p] = make_double2(a0.x - a2.x, a0.y - a2.y);
+        out[j + 3 * p] = make_double2(a1.x - a3.x, a1.y - a3.y);
+        cur ^= 1;
         __syncthreads();
     }
+    const double2 *Z = buf[cur];
     for (int f = tid; f < NBINS; f += 256) {
-        const float re = (float)x[f].x, im = (float)x[f].y;     // complex64 storage
+        const double2 zk = Z[f & (N2 - 1)];
+        const double2 zr = Z[(N2 - f) & (N2 - 1)];
+        const double2 E = make_double2(0.5 * (zk.x + zr.x), 0.5 * (zk.y - zr.y));    // (Zk + conj Zr)/2
+        const double2 O = make_double2(0.5 * (zk.x - zr.x), 0.5 * (zk.y + zr.y));    // (Zk - conj Zr)/2
+        const double2 D = cmul(tw2048(twiddle, f), O);
+        const float re = (float)(E.x + D.y), im = (float)(E.y - D.x);               // complex64 storage
         const float mag = hypotf(re, im);                       // np.abs on complex64
         pw[f] = mag * mag;                                      // ** 2.0 in float32
     }
     __syncthreads();
-    for (int m = tid; m < n_mels; m += 256) {
-        const float *row = basis + (size_t)m * NBINS;
+    // mel projection: four lanes per filter, lane q takes bins lo+q, lo+q+4, ... (ascending), the four
+    // partial sums are combined as (p0 + p1) + (p2 + p3)
+    for (int m0 = 0; m0 < n_mels; m0 += 64) {
+        const int m = m0 + (tid >> 2), q = tid & 3;
         float acc = 0.0f;
-        for (int f = lo[m]; f < hi[m]; ++f) acc += row[f] * pw[f];
-        power_out[((size_t)b * n_mels + m) * n_frames + t] = acc;
+        if (m < n_mels) {
+            const float *row = basis + (size_t)m * NBINS;
+            const int h = hi[m];
+            for (int f = lo[m] + q; f < h; f += 4) acc += row[f] * pw[f];
+        }
+        acc += __shfl_xor(acc, 1);
+        acc += __shfl_xor(acc, 2);
+        if (m < n_mels && q == 0) power_out[((size_t)b * n_mels + m) * n_frames + t] = acc;
     }
 }
 
