@@ -1,0 +1,71 @@
+"""Seeded random configurations of the reservoir path on the GPU against the C oracle: odd sizes (N not a
+multiple of 64, C not a multiple of 32, T not a multiple of 4), every feature set, heterogeneous leak,
+refractory 0-5, quiet and saturated drive, both kernels, the chosen layout and a forced one.  Everything
+(spike matrix, float32 membrane trace, features) must be bit-identical."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def torch_cuda():
+    import torch
+    assert torch.cuda.is_available(), "GPU tests need a HIP device"
+    from lsm_speech_classifier_amd import _lib
+    _lib.require_gpu()
+    return torch
+
+ALL_KEYS = ['spike_counts', 'spike_variances', 'mean_spike_times', 'first_spike_times',
+            'last_spike_times', 'mean_isi', 'isi_variances', 'burst_counts']
+
+
+def _cases(n_cases, seed):
+    rng = np.random.RandomState(seed)
+    for i in range(n_cases):
+        n = int(rng.randint(40, 700))
+        k = int(2 * rng.randint(2, max(3, min(n // 4, 60))))
+        c = int(rng.randint(1, 200))
+        t = int(rng.choice([1, 7, 37, 100, 255, 400]))
+        yield dict(
+            n=n, k=k, c=c, t=t, n_out=int(rng.randint(1, n + 1)),
+            density=float(rng.choice([0.0, 0.02, 0.2, 0.6, 1.0])),
+            mult=float(rng.choice([0.3, 0.6, 1.5, 4.0])),
+            refr=int(rng.randint(0, 6)),
+            div=(None if rng.rand() < 0.5 else float(rng.choice([2.0, 5.0, 20.0]))),
+            keys=[ALL_KEYS[j] for j in sorted(rng.choice(8, size=rng.randint(1, 9), replace=False))],
+            wpc=int(rng.choice([1, 2, 4, 8, 16])), seed=1000 * seed + i)
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_random_configurations_match_the_oracle(torch_cuda, oracle_c, seed):
+    from lsm_speech_classifier_amd import _lib, reservoir as R, snn, synth
+    from oracle import ref_numpy as O
+    spikes = 0
+    for case in _cases(16, seed):
+        rasters = synth.bernoulli_raster(3, case["c"], case["t"], case["density"], seed=case["seed"])
+        rasters[1] = (rasters[1] * 201).astype(np.uint8)                # any non-zero byte is a spike
+        wc = O.w_critico(case["k"], 2.0, case["refr"], rasters)
+        p = R.SimulationParams(num_neurons=case["n"], num_output_neurons=case["n_out"],
+                               small_world_graph_k=case["k"], mean_weight=wc * case["mult"],
+                               refractory_period=case["refr"], leak_variance_divisor=case["div"])
+        res = R.build_reservoir(p, case["c"])
+        net = snn.SNN(None, reservoir=res)
+        for kernel in ("dense", "sparse"):
+            net.set_kernel(kernel)
+            for wpc in (0, case["wpc"]):
+                try:
+                    f, sm, vt = net.run_batch(rasters, case["keys"], want_spike_matrix=True,
+                                              want_v_trace=True, waves_per_clip=wpc)
+                except _lib.LsmHipError as e:          # a forced layout this reservoir does not have
+                    assert wpc != 0 and "layout" in str(e), (case, str(e))
+                    continue
+                f, sm, vt = f.cpu().numpy(), sm.cpu().numpy(), vt.cpu().numpy()
+                for b in range(len(rasters)):
+                    f_ref, sm_ref, vt_ref = oracle_c.lif_run(res, rasters[b], case["keys"], want_trace=True)
+                    msg = f"{case} kernel {kernel} wpc {wpc} clip {b}"
+                    np.testing.assert_array_equal(sm[b], sm_ref, err_msg=msg)
+                    np.testing.assert_array_equal(vt[b], vt_ref, err_msg=msg)
+                    np.testing.assert_array_equal(f[b], f_ref, err_msg=msg)
+                    spikes += int(sm_ref.sum())
+    assert spikes > 10000                                  # the cases do exercise spiking networks
