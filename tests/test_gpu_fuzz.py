@@ -69,3 +69,37 @@ def test_random_configurations_match_the_oracle(torch_cuda, oracle_c, seed):
                     np.testing.assert_array_equal(f[b], f_ref, err_msg=msg)
                     spikes += int(sm_ref.sum())
     assert spikes > 10000                                  # the cases do exercise spiking networks
+
+
+@pytest.mark.parametrize("n_samples,nw", [(12000, 4), (16000, 3), (24000, 2), (48000, 1), (13000, 4)])
+def test_front_end_other_clip_lengths_and_window_overlaps(torch_cuda, oracle_c, n_samples, nw):
+    """The reference computes hop_time from the clip length (create_dataset.py:50), so other lengths change
+    how many analysis windows overlap: 4, 3, 2 or 1 window kernels, hops that are not multiples of 8 (13000
+    samples: hop 130), odd filter counts, several thresholds and redundancy -- all against the C oracle."""
+    from lsm_speech_classifier_amd import frontend, synth
+    from oracle import ref_numpy as O
+    rng = np.random.RandomState(n_samples)
+    F = int(rng.choice([2, 33, 64, 65, 130]))
+    thr = sorted(float(x) for x in rng.choice(np.arange(0.05, 0.99, 0.05), size=rng.randint(1, 6), replace=False))
+    gap = float(rng.choice([0.02, 0.05, 0.1]))
+    red = int(rng.randint(1, 4))
+    fe = frontend.SpikeFrontEnd(F, "gammatone", redundancy=red, thresholds=thr, gap=gap, n_samples=n_samples)
+    assert (fe.nwin + fe.hop - 1) // fe.hop == nw
+    t = np.arange(n_samples) / 16000.0
+    audio = np.stack([
+        (0.3 * np.sin(2 * np.pi * (200 + 900 * t) * t) + 0.02 * rng.standard_normal(n_samples)),
+        0.1 * rng.standard_normal(n_samples),
+        np.zeros(n_samples)]).astype(np.float32)
+    coefs = O.gammatone_coefs(16000, F, 50)
+    db, spec = fe.spectrogram_db(audio, want_spec=True)
+    raster, norm = fe.spikes_from_db(db, want_norm=True)
+    spec, norm, raster = spec.cpu().numpy(), norm.cpu().numpy(), raster.cpu().numpy()
+    assert raster.shape == (3, F * red, 100 * len(thr))
+    for b in range(3):
+        s_ref = oracle_c.gammatone_spec(audio[b], coefs, fe.nwin, fe.hop, fe.ncols)
+        np.testing.assert_array_equal(spec[b], s_ref)
+        n_ref = oracle_c.normalise_resize(oracle_c.gammatone_db(s_ref))
+        np.testing.assert_allclose(norm[b], n_ref, rtol=0, atol=1e-13)
+        r_own = oracle_c.encode_hysteresis(norm[b], thr, gap)              # exact on the GPU's own input
+        np.testing.assert_array_equal(raster[b], np.repeat(r_own, red, axis=0))
+    assert not raster[2].any()                                             # silence stays silent
