@@ -16,7 +16,7 @@ def _audio(n, seed):
     return a
 
 
-@pytest.mark.parametrize("n_mels", [40, 128])
+@pytest.mark.parametrize("n_mels", [13, 40, 80, 128])
 def test_mel_frontend_matches_oracle(n_mels):
     import torch
     from lsm_speech_classifier_amd import frontend
