@@ -164,6 +164,12 @@ def main():
     res = reservoir.build_reservoir(params, fe.n_channels)
     net = snn.SNN(params, reservoir=res, device=dev)
     n_feat = len(FEATURE_SET) * cfg["n_out"]
+    # Layout of a clip in the reservoir kernel.  The library's own choice (8 waves per clip at B = 256)
+    # minimises the duration of a lone launch; inside the overlapped pipeline, which is bound by vector-ALU
+    # issue, 4 waves per clip (4 neurons per lane) spend fewer instructions on per-wave overheads and the
+    # whole pipeline is 3.5 % faster in a same-box A/B (exp/combo_sweep.sh).
+    if args.waves_per_clip == 0 and max(1, args.streams) > 1 and cfg["N"] <= 1024 and args.stage == "full":
+        args.waves_per_clip = 4
     lay = net.layout(B, fe.n_steps, args.waves_per_clip)
 
     ev_pairs = []
@@ -283,7 +289,21 @@ def main():
             pairs.append(e0.elapsed_time(e1))
         fe_ms = sorted(pairs)[len(pairs) // 2]
     serial_ms = None
+    lone_ms = None
     if args.stage != "frontend" and rank == 0:
+        def lone_launch(wpc):
+            times = []
+            for _ in range(5):
+                a0, a1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                torch.cuda.synchronize()
+                a0.record()
+                net.run_batch(rasters0, FEATURE_SET, waves_per_clip=wpc)
+                a1.record()
+                torch.cuda.synchronize()
+                times.append(a0.elapsed_time(a1))
+            return sorted(times)[len(times) // 2]
+        # the library's own layout for a lone launch (8 waves per clip at B = 256), for reference
+        lone_ms = lone_launch(0)
         pairs = []
         for _ in range(5):
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -342,7 +362,12 @@ def main():
                 "compulsory_gbs": round(compulsory * B / (lif_ms * 1e-3) / 1e9, 3),
                 "kernel_clips_per_s": round(B / (lif_ms * 1e-3), 1),
                 "note": "kernel_ms is the HIP-event average over the timed region, where launches of "
-                        "consecutive steps overlap on the GPU; idle_gpu_* is the same launch alone",
+                        "consecutive steps overlap on the GPU; idle_gpu_* is the same launch (same layout) alone; "
+                        "lone_launch_* is a lone launch in the layout the library picks for it",
+                "lone_launch_kernel_ms": None if lone_ms is None else round(lone_ms, 4),
+                "lone_launch_frac": None if lone_ms is None else
+                round(per_clip * B / (lone_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
+                "lone_launch_waves_per_clip": net.layout(B, fe.n_steps, 0)["waves_per_clip"],
                 "idle_gpu_kernel_ms": None if serial_ms is None else round(serial_ms, 4),
                 "idle_gpu_frac": None if serial_ms is None else
                 round(per_clip * B / (serial_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
