@@ -117,7 +117,7 @@ int lsm_reservoir_create(lsm_reservoir **out, int num_neurons, int n_channels,
 int lsm_reservoir_destroy(lsm_reservoir *h);
 
 /* Kernel used by lsm_reservoir_run for this handle: 0 = choose (dense presynaptic rows with register
- * accumulation for reservoirs of <= 8192 neurons, else the sparse CSC scatter), 1 = sparse, 2 = dense.
+ * accumulation), 1 = sparse CSC scatter through LDS, 2 = dense rows.  num_neurons <= 8192.
  * Both produce bit-identical results (SPEC.md §3). */
 int lsm_reservoir_set_kernel(lsm_reservoir *h, int mode);
 

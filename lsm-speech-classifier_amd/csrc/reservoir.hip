@@ -97,7 +97,9 @@ int lsm_reservoir_create(lsm_reservoir **out, int num_neurons, int n_channels,
     LSM_REQUIRE(out != nullptr, "lsm_reservoir_create: out is null");
     *out = nullptr;
     const int N = num_neurons, C = n_channels;
-    LSM_REQUIRE(N >= 1 && N <= 16384, "num_neurons=%d outside [1, 16384]", N);
+    // 8192: beyond that the per-clip LDS image (counts, spike lists, features, input bits) of neither kernel
+    // fits the 160 KB of a CU
+    LSM_REQUIRE(N >= 1 && N <= 8192, "num_neurons=%d outside [1, 8192]", N);
     LSM_REQUIRE(C >= 1 && C <= 65535, "n_channels=%d outside [1, 65535]", C);
     LSM_REQUIRE(n_out >= 1 && n_out <= N, "num_output_neurons=%d outside [1, %d]", n_out, N);
     LSM_REQUIRE(theta > 0.0f, "membrane_threshold must be > 0");
@@ -205,7 +207,7 @@ int lsm_reservoir_create(lsm_reservoir **out, int num_neurons, int n_channels,
     }
     // dense presynaptic rows for the register-accumulating kernel (lif_dense.h): N x ld floats, only
     // up to N = 8192 (4 MB at N = 1000: L2; 64 MB at N = 4000 and 262 MB at N = 8000: Infinity Cache / HBM)
-    if (N <= 8192) {
+    {
         int ldmax = 0;
         for (const auto &v : h->var)
             if (v.wpc) ldmax = std::max(ldmax, v.sl * 64 * v.wpc);
@@ -225,7 +227,7 @@ int lsm_reservoir_set_kernel(lsm_reservoir *h, int mode)
 {
     LSM_REQUIRE(h != nullptr, "lsm_reservoir_set_kernel: null handle");
     LSM_REQUIRE(mode >= 0 && mode <= 2, "mode must be 0 (auto), 1 (sparse) or 2 (dense)");
-    LSM_REQUIRE(mode != 2 || h->wt != nullptr, "dense rows are only built for reservoirs of <= 8192 neurons");
+    LSM_REQUIRE(mode != 2 || h->wt != nullptr, "this reservoir has no dense row table");
     h->mode = mode;
     return LSM_OK;
 }

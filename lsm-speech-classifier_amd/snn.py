@@ -120,7 +120,7 @@ class SNN:
         }
 
     def set_kernel(self, mode: str = "auto"):
-        """'auto' (dense presynaptic rows for N <= 8192, else sparse), 'sparse' or 'dense'."""
+        """'auto' (dense presynaptic rows with register accumulation), 'sparse' (CSC scatter through LDS) or 'dense'."""
         _lib.check(self.lib.lsm_reservoir_set_kernel(self._handle, {"auto": 0, "sparse": 1, "dense": 2}[mode]),
                    "lsm_reservoir_set_kernel")
 

@@ -103,3 +103,30 @@ def test_front_end_other_clip_lengths_and_window_overlaps(torch_cuda, oracle_c, 
         r_own = oracle_c.encode_hysteresis(norm[b], thr, gap)              # exact on the GPU's own input
         np.testing.assert_array_equal(raster[b], np.repeat(r_own, red, axis=0))
     assert not raster[2].any()                                             # silence stays silent
+
+
+def test_reservoir_size_limit_is_enforced_at_create_time(torch_cuda, oracle_c):
+    """8192 neurons is the limit (the per-clip LDS image of a larger reservoir fits no CU): 8192 works and is
+    bit-exact, 8193 is refused with a message when the reservoir is created, not at run time."""
+    from lsm_speech_classifier_amd import _lib, reservoir as R, snn, synth
+    from oracle import ref_numpy as O
+    c, t, k = 20, 40, 24
+    rasters = synth.bernoulli_raster(2, c, t, 0.3, seed=4)
+    wc = O.w_critico(k, 2.0, 2, rasters)
+    big = R.build_reservoir(R.SimulationParams(num_neurons=8193, num_output_neurons=100, small_world_graph_k=k,
+                                               mean_weight=wc * 2.0), c)
+    with pytest.raises(_lib.LsmHipError, match="8192"):
+        snn.SNN(None, reservoir=big)
+    res = R.build_reservoir(R.SimulationParams(num_neurons=8192, num_output_neurons=300, small_world_graph_k=k,
+                                               mean_weight=wc * 2.0), c)
+    net = snn.SNN(None, reservoir=res)
+    keys = ["spike_counts", "mean_isi", "burst_counts"]
+    for kernel in ("dense", "sparse"):
+        net.set_kernel(kernel)
+        f, sm, vt = net.run_batch(rasters, keys, want_spike_matrix=True, want_v_trace=True)
+        for b in range(2):
+            f_ref, sm_ref, vt_ref = oracle_c.lif_run(res, rasters[b], keys, want_trace=True)
+            np.testing.assert_array_equal(sm[b].cpu().numpy(), sm_ref)
+            np.testing.assert_array_equal(vt[b].cpu().numpy(), vt_ref)
+            np.testing.assert_array_equal(f[b].cpu().numpy(), f_ref)
+            assert sm_ref.any()
