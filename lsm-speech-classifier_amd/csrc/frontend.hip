@@ -464,7 +464,7 @@ LSM_API int lsm_gammatone_spec_f64(const float *audio, int n_clips, int n_sample
     // that overlap on other streams spread over the free CUs instead of stacking their waves on the
     // SIMDs an earlier launch already occupies (measured at 256 clips x 128 filters, 3 streams:
     // 0.85 -> 0.68 ms per launch, whole pipeline 1.18 -> 0.95 ms).  The other half of the LDS
-    // stays free for a reservoir workgroup.  Launches with more workgroups than CUs need several
+    // stays free for the reservoir workgroups (21.5 KB each at cfg2; two or three per CU is best).  Launches with more workgroups than CUs need several
     // per CU and get no reservation.
     int lds = 0;
     {
