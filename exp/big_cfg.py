@@ -27,6 +27,8 @@ for wpc in ([0] if len(sys.argv) < 5 else [int(x) for x in sys.argv[4].split(","
     per_clip = fe.n_channels * 400 + f.shape[1] * 4 + 400 * res.csr_bytes() / B
     print(f"wpc {wpc or net.layout(B,400)['waves_per_clip']}: LIF {ms:.2f} ms for {B} clips = {B/ms*1e3:.0f} clips/s; streamed {per_clip*B/ms/1e6:.1f} GB/s ({per_clip*B/ms/1e6/8000*100:.2f}% of 8 TB/s); "
           f"spikes/out-neuron/clip {float(f[:, :cfg['n_out']].mean()):.2f}", flush=True)
+if ncheck <= 0:
+    sys.exit(0)
 rn = r[:ncheck].cpu().numpy()
 t0 = time.time(); ref = cport.lif_run_batch(res, rn, bench.FEATURE_SET, n_threads=min(ncheck, os.cpu_count()))
 print(f"oracle {ncheck} clip(s) in {time.time()-t0:.1f}s; bit-exact: {np.array_equal(ref, f[:ncheck].cpu().numpy())}", flush=True)
