@@ -356,6 +356,12 @@ def main():
                 "bound": "hbm", "kernel": "lif_dense_kernel" if cfg["N"] <= 8192 else "lif_kernel", "achieved": round(achieved, 2),
                 "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
                 "traffic": traffic, "kernel_ms": round(lif_ms, 4),
+                # the measured memory-side bytes over the duration of the launch they were measured on (a lone
+                # launch, one stream): what the kernel really pulls through the memory side of L2
+                "traffic_gbs": None if (traffic is None or serial_ms is None) else
+                round(traffic / (serial_ms * 1e-3) / 1e9, 1),
+                "traffic_frac_of_peak": None if (traffic is None or serial_ms is None) else
+                round(traffic / (serial_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                 "bytes_per_clip": round(per_clip, 1),
                 "variant": "streamed (C*T + 4*F_feat + T*|W|/B, SURVEY.md 8d); |W| = 8 B x nnz",
                 "compulsory_bytes_per_clip": round(compulsory, 1),

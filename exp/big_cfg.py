@@ -9,8 +9,7 @@ name = sys.argv[1]; B = int(sys.argv[2]); ncheck = int(sys.argv[3]) if len(sys.a
 cfg = bench.CONFIGS[name]
 t0 = time.time()
 fe = frontend.SpikeFrontEnd(cfg["n_filters"], "gammatone")
-audio = bench.make_audio(cfg["audio"], min(B, 64), 1234)
-audio = np.tile(audio, (-(-B // len(audio)), 1))[:B]
+audio = bench.make_audio(cfg["audio"], B, 1234)          # B distinct clips (tiled copies would share L2 lines)
 r = fe.encode(torch.from_numpy(audio).cuda()); torch.cuda.synchronize()
 print(f"front end ok {tuple(r.shape)} density {float(r.float().mean()):.3f} ({time.time()-t0:.1f}s)", flush=True)
 wc = bench.w_critico(cfg["k"], 2.0, 2, r)

@@ -74,6 +74,12 @@ def main():
     }
     if "TCC_HIT_sum" in mean and "TCC_MISS_sum" in mean:
         traffic[key + "_l2_hit_rate"] = mean["TCC_HIT_sum"] / (mean["TCC_HIT_sum"] + mean["TCC_MISS_sum"])
+    # _keep_large: the large-configuration entries come from exp/big_traffic.sh (profiles/r01_big_traffic.json)
+    old_path = os.path.join(DST, "lif_traffic.json")
+    if os.path.exists(old_path):
+        for k, v in json.load(open(old_path)).items():
+            if k.startswith(("cfg4_", "cfg5_", "_how_large")):
+                traffic.setdefault(k, v)
     json.dump(traffic, open(os.path.join(DST, "lif_traffic.json"), "w"), indent=1)
     print(json.dumps(traffic, indent=1))
     for f in ("kernel_stats.csv", "kernel_stats_serial.csv"):
