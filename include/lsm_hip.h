@@ -116,9 +116,11 @@ int lsm_reservoir_create(lsm_reservoir **out, int num_neurons, int n_channels,
                          int burst_isi_max);
 int lsm_reservoir_destroy(lsm_reservoir *h);
 
-/* Kernel used by lsm_reservoir_run for this handle: 0 = choose (dense presynaptic rows with register
- * accumulation), 1 = sparse CSC scatter through LDS, 2 = dense rows.  num_neurons <= 8192.
- * Both produce bit-identical results (SPEC.md §3). */
+/* Kernel used by lsm_reservoir_run for this handle: 0 = choose (register accumulation over dense
+ * presynaptic rows; over band rows -- dense ring window + list of the synapses outside it -- for ring-like
+ * reservoirs whose dense table exceeds the Infinity Cache), 1 = sparse CSC scatter through LDS, 2 = dense rows, 3 = band rows
+ * (refused when the reservoir is not ring-like).  All produce bit-identical results (SPEC.md §3).
+ * num_neurons <= 8192. */
 int lsm_reservoir_set_kernel(lsm_reservoir *h, int mode);
 
 /* Replaces, for a whole batch, the per-clip loop body of extract_all_features

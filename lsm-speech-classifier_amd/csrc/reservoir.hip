@@ -43,6 +43,8 @@ struct Variant {            // per waves-per-clip layout
     int *oslot = nullptr;
     uint32_t *in_ent = nullptr;
     uint32_t *inmask = nullptr;      // (npad, 4) input-channel masks, only when C <= 128 and sl <= 4
+    uint2 *rem = nullptr;            // band format: (N, wpc, rem_e) synapses outside the ring window
+    int rem_e = 0;                   // 0: this layout has no band format (a list would exceed 64 entries)
 };
 
 }  // namespace
@@ -56,7 +58,10 @@ struct lsm_reservoir {
     uint32_t *rowptr = nullptr;
     float *wt = nullptr;    // dense rows by presynaptic neuron (N, ld), small reservoirs only
     int ld = 0;
-    int mode = 0;           // 0 auto, 1 sparse (CSC scatter through LDS), 2 dense rows
+    // band format (lif_dense.h, BAND): dense ring window of 2*band_h+1 targets per presynaptic neuron
+    float *band = nullptr;
+    int band_ld = 0, band_h = 0;
+    int mode = 0;           // 0 auto, 1 sparse (CSC scatter through LDS), 2 dense rows, 3 band rows
     Variant var[5];         // wpc = 1, 2, 4, 8, 16 (wpc == 0: not available)
 };
 
@@ -66,6 +71,7 @@ static int free_reservoir(lsm_reservoir *h)
     if (h->syn) (void)hipFree(h->syn);
     if (h->rowptr) (void)hipFree(h->rowptr);
     if (h->wt) (void)hipFree(h->wt);
+    if (h->band) (void)hipFree(h->band);
     for (auto &v : h->var) {
         if (v.seg) (void)hipFree(v.seg);
         if (v.segoff) (void)hipFree(v.segoff);
@@ -73,6 +79,7 @@ static int free_reservoir(lsm_reservoir *h)
         if (v.oslot) (void)hipFree(v.oslot);
         if (v.in_ent) (void)hipFree(v.in_ent);
         if (v.inmask) (void)hipFree(v.inmask);
+        if (v.rem) (void)hipFree(v.rem);
     }
     delete h;
     return LSM_OK;
@@ -217,6 +224,60 @@ int lsm_reservoir_create(lsm_reservoir **out, int num_neurons, int n_channels,
         if ((rc = upload(&h->wt, wt))) { free_reservoir(h); return rc; }
         h->ld = ldmax;
     }
+    // Band format for ring-like graphs: window half-width = half the mean out-degree (k/2 of a small-world
+    // graph), used when the window is a real saving (< half a row) and holds most of the synapses.
+    {
+        const int H = (int)((nnz / (size_t)N + 1) / 2);
+        const int wd = 2 * H + 1;
+        size_t inside = 0;
+        for (int j = 0; j < N; ++j)
+            for (int e = csc_ptr[j]; e < csc_ptr[j + 1]; ++e) {
+                int q = csc_post[e] - (j - H);
+                q = q < 0 ? q + N : (q >= N ? q - N : q);
+                inside += q < wd;
+            }
+        if (H >= 1 && 2 * wd <= N && nnz > 0 && inside * 10 >= nnz * 6) {
+            const int bld = (wd + 3) / 4 * 4;
+            std::vector<float> band((size_t)N * bld, 0.0f);
+            for (int j = 0; j < N; ++j)
+                for (int e = csc_ptr[j]; e < csc_ptr[j + 1]; ++e) {
+                    int q = csc_post[e] - (j - H);
+                    q = q < 0 ? q + N : (q >= N ? q - N : q);
+                    if (q < wd) band[(size_t)j * bld + q] = csc_w[e];
+                }
+            if ((rc = upload(&h->band, band))) { free_reservoir(h); return rc; }
+            h->band_ld = bld; h->band_h = H;
+            for (auto &v : h->var) {
+                if (!v.wpc) continue;
+                const int npw = v.sl * 64;
+                std::vector<int> cnt((size_t)N * v.wpc, 0);
+                int emax = 0;
+                for (int j = 0; j < N; ++j)
+                    for (int e = csc_ptr[j]; e < csc_ptr[j + 1]; ++e) {
+                        int q = csc_post[e] - (j - H);
+                        q = q < 0 ? q + N : (q >= N ? q - N : q);
+                        if (q >= wd) emax = std::max(emax, ++cnt[(size_t)j * v.wpc + csc_post[e] / npw]);
+                    }
+                const int E = std::max(4, (emax + 3) / 4 * 4);
+                if (E > 64) continue;                         // one lane per entry: not for this layout
+                std::vector<uint2> rem((size_t)N * v.wpc * E, make_uint2(0xFFFFFFFFu, 0u));
+                std::fill(cnt.begin(), cnt.end(), 0);
+                for (int j = 0; j < N; ++j)
+                    for (int e = csc_ptr[j]; e < csc_ptr[j + 1]; ++e) {
+                        int q = csc_post[e] - (j - H);
+                        q = q < 0 ? q + N : (q >= N ? q - N : q);
+                        if (q < wd) continue;
+                        const int wv = csc_post[e] / npw;
+                        uint32_t bits;
+                        std::memcpy(&bits, &csc_w[e], 4);
+                        rem[((size_t)j * v.wpc + wv) * E + cnt[(size_t)j * v.wpc + wv]++] =
+                            make_uint2((uint32_t)(csc_post[e] - wv * npw), bits);
+                    }
+                if ((rc = upload(&v.rem, rem))) { free_reservoir(h); return rc; }
+                v.rem_e = E;
+            }
+        }
+    }
     *out = h;
     return LSM_OK;
 }
@@ -226,7 +287,8 @@ extern "C" __attribute__((visibility("default")))
 int lsm_reservoir_set_kernel(lsm_reservoir *h, int mode)
 {
     LSM_REQUIRE(h != nullptr, "lsm_reservoir_set_kernel: null handle");
-    LSM_REQUIRE(mode >= 0 && mode <= 2, "mode must be 0 (auto), 1 (sparse) or 2 (dense)");
+    LSM_REQUIRE(mode >= 0 && mode <= 3, "mode must be 0 (auto), 1 (sparse), 2 (dense) or 3 (band)");
+    LSM_REQUIRE(mode != 3 || h->band != nullptr, "this reservoir has no band format (not ring-like enough)");
     LSM_REQUIRE(mode != 2 || h->wt != nullptr, "this reservoir has no dense row table");
     h->mode = mode;
     return LSM_OK;
@@ -261,6 +323,16 @@ static size_t lif_lds_bytes(const lsm_reservoir *h, const Variant &v, int T)
     return lif_lds_core(h, v, T) + (lif_seg_in_lds(h, v, T) ? lif_seg_bytes(h, v) : 0);
 }
 
+// band rows: on request, or by default when the dense table no longer fits the 256 MB Infinity Cache -- there
+// the row gathers are bound by HBM bytes and the band format's extra instructions pay (N = 8000: 79 vs 102 ms
+// per 512 clips); while the dense table is cache resident it is the faster one (N = 4000: 13 vs 23 ms)
+constexpr size_t BAND_AUTO_MIN_DENSE_BYTES = (size_t)192 << 20;
+static bool want_band(const lsm_reservoir *h)
+{
+    if (h->band == nullptr) return false;
+    if (h->mode == 3) return true;
+    return h->mode == 0 && (size_t)h->N * (size_t)h->ld * 4 > BAND_AUTO_MIN_DENSE_BYTES;
+}
 static bool use_dense(const lsm_reservoir *h) { return h->wt != nullptr && h->mode != 1; }
 
 static size_t dense_lds_bytes(const lsm_reservoir *h, const Variant &v, int T)
@@ -322,9 +394,15 @@ int lsm_reservoir_run(const lsm_reservoir *h, const uint8_t *spikes_u8, int n_cl
     for (int k = 0; k < n_keys; ++k)
         LSM_REQUIRE(key_ids[k] >= 0 && key_ids[k] < 8, "key id %d out of range", key_ids[k]);
     if (use_dense(h)) {
-        lsm_lif::dense_fn_t dfn = v->inmask       ? lsm_lif::pick_dense_2(v->sl, v->wpc)
-                                  : lif_inreg(*v) ? lsm_lif::pick_dense_1(v->sl, v->wpc)
-                                                  : lsm_lif::pick_dense_0(v->sl, v->wpc);
+        const bool band = want_band(h) && v->rem_e > 0;
+        LSM_REQUIRE(band || h->mode != 3, "the band format has no list layout for %d waves per clip", v->wpc);
+        lsm_lif::dense_fn_t dfn =
+            band ? (v->inmask       ? lsm_lif::pick_band_2(v->sl, v->wpc)
+                    : lif_inreg(*v) ? lsm_lif::pick_band_1(v->sl, v->wpc)
+                                    : lsm_lif::pick_band_0(v->sl, v->wpc))
+                 : (v->inmask       ? lsm_lif::pick_dense_2(v->sl, v->wpc)
+                    : lif_inreg(*v) ? lsm_lif::pick_dense_1(v->sl, v->wpc)
+                                    : lsm_lif::pick_dense_0(v->sl, v->wpc));
         LSM_REQUIRE(dfn != nullptr, "no dense kernel for SL=%d WPC=%d", v->sl, v->wpc);
         lsm_lif::DenseArgs d;
         d.N = h->N; d.C = h->C; d.T = n_steps; d.B = n_clips;
@@ -333,6 +411,7 @@ int lsm_reservoir_run(const lsm_reservoir *h, const uint8_t *spikes_u8, int n_cl
         d.theta = h->theta; d.w_in = h->w_in;
         d.raster = spikes_u8; d.wt = h->wt; d.leak = v->leak; d.oslot = v->oslot; d.in_ent = v->in_ent;
         d.inmask = v->inmask;
+        d.band = h->band; d.rem = v->rem; d.band_ld = h->band_ld; d.band_h = h->band_h; d.rem_e = v->rem_e;
         d.n_keys = n_keys;
         for (int k = 0; k < 8; ++k) d.key_ids[k] = k < n_keys ? key_ids[k] : 0;
         d.features = features_out; d.spike_matrix = spike_matrix_out; d.v_trace = v_trace_out;

@@ -120,9 +120,10 @@ class SNN:
         }
 
     def set_kernel(self, mode: str = "auto"):
-        """'auto' (dense presynaptic rows with register accumulation), 'sparse' (CSC scatter through LDS) or 'dense'."""
-        _lib.check(self.lib.lsm_reservoir_set_kernel(self._handle, {"auto": 0, "sparse": 1, "dense": 2}[mode]),
-                   "lsm_reservoir_set_kernel")
+        """'auto' (register accumulation over dense presynaptic rows; over band rows for ring-like
+        reservoirs whose dense table exceeds the Infinity Cache), 'sparse' (CSC scatter through LDS), 'dense' or 'band'."""
+        _lib.check(self.lib.lsm_reservoir_set_kernel(
+            self._handle, {"auto": 0, "sparse": 1, "dense": 2, "band": 3}[mode]), "lsm_reservoir_set_kernel")
 
     def layout(self, n_clips: int, n_steps: int, waves_per_clip: int = 0):
         wpc, sl, lds = C.c_int(), C.c_int(), C.c_int()
