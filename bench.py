@@ -138,8 +138,17 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault("MASTER_PORT", "29531")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        # rehearsal switches for a 1-GPU box (never used by the driver): LSM_BENCH_BACKEND=gloo exchanges
+        # through the host, LSM_BENCH_SHARE_GPU=1 puts every rank on cuda:0 -- together they run the
+        # multi-rank code path (rank > 0, uneven timing, gather order) with several processes on one card
+        backend = os.environ.get("LSM_BENCH_BACKEND", "nccl")
+        if os.environ.get("LSM_BENCH_SHARE_GPU") == "1":
+            local_rank = 0
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
     else:
         torch.cuda.set_device(0)
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
