@@ -9,28 +9,26 @@ BASELINE.json configs[1]: 128 gammatone filters, 1000-neuron reservoir, batch 25
 `original` feature set, multiplier 0.6.  Clips shard across ranks (weak scaling, no data-path
 collective except the final feature gather the reference's single-process run implies).
 
-Prints ONE JSON line on rank 0 with the contract keys plus `roofline` (LIF kernel, algorithmic
-bytes of SURVEY.md §8(d) / measured HIP-event time) and, at N=1, `cpu_baseline` (the C oracle
-timed on the host cores on a bounded sample of the same workload).
+This file only TIMES the path: the overlapped pipeline itself (stream rotation, hardware-queue count,
+reservoir layout for a shared GPU) is `lsm_speech_classifier_amd.pipeline.HotPath`, the same object the
+drop-in scripts use.  With --gpus N > 1 and no launcher environment it starts N fresh rank processes
+itself (before anything touches the GPU) and exits with their status.
+
+Prints ONE JSON line on rank 0 with the contract keys plus `roofline` (reservoir kernel, algorithmic
+bytes of SURVEY.md §8(d) / measured HIP-event time; `dominant_kernel_by_time` = the float64 filterbank)
+and, at N=1, `cpu_baseline` (the C oracle timed on the host cores on a bounded sample of the workload).
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
-
-# The steps rotate over several HIP streams; the runtime multiplexes streams onto 4 hardware queues by
-# default and kernels of streams that share a queue serialise.  With 8 or more queues six streams overlap
-# (measured at cfg2: 0.96 -> 0.82 ms per step; exp/hwq_sweep.sh); 12 also leave RCCL's stream a queue of
-# its own when N > 1 (exp/dist_rehearsal.sh).  Must be set before HIP initialises.
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "12")
-
-import numpy as np
-import torch
 
 CONFIGS = {
     # name: (n_filters, filterbank, N, k, N_out, batch per GPU, audio kind)
@@ -46,10 +44,68 @@ CONFIGS = {
 FEATURE_SET = ['spike_counts', 'spike_variances', 'mean_spike_times', 'mean_isi', 'isi_variances']
 MULTIPLIER = 0.6
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8 TB/s spec
+F64_UNFUSED_PEAK_TOPS = 39.3   # one float64 operation per lane and instruction, all 1024 SIMDs (exp/ubench_f64.hip)
 
 
+def parse_args(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=12)
+    ap.add_argument("--config", default="cfg2", choices=sorted(CONFIGS))
+    ap.add_argument("--batch", type=int, default=0, help="clips per GPU (0 = the config's)")
+    ap.add_argument("--waves-per-clip", type=int, default=None,
+                    help="reservoir layout (default: the library chooses, knowing whether steps overlap)")
+    ap.add_argument("--kernel", default="auto", choices=["auto", "dense", "ring", "sparse"])
+    ap.add_argument("--stage", default="full", choices=["full", "reservoir", "frontend"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--from-host", action="store_true",
+                    help="every step first copies its audio batch from pinned host memory (PCIe-inclusive "
+                         "rate; never the contract's `value`, which is quoted on HBM-resident inputs)")
+    ap.add_argument("--streams", type=int, default=0,
+                    help="HIP streams the steps rotate over (0 = the pipeline's default; 1 = serial)")
+    return ap.parse_args(argv)
+
+
+# ------------------------------------------------------------------------------ launcher ----
+def spawn_ranks(n: int) -> int:
+    """`python bench.py --gpus N` without torchrun: start N fresh rank processes of this script (the parent
+    has not touched the GPU and never does), one per GPU, and return the worst exit status.  Rank 0 prints
+    the JSON line on the inherited stdout."""
+    with socket.socket() as s:                      # a free rendezvous port
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    rc = 0
+    for p in procs:
+        rc = max(rc, abs(p.wait()))
+    return rc
+
+
+def spawn_check():
+    """LSM_BENCH_SPAWN_ONLY=1: the launcher path without a GPU -- every rank joins a gloo group, the ranks
+    are summed, rank 0 reports (tests/test_bench_spawn.py)."""
+    import torch
+    import torch.distributed as dist
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    dist.init_process_group("gloo")
+    t = torch.tensor([float(rank)])
+    dist.all_reduce(t)
+    dist.barrier()
+    if rank == 0:
+        print(json.dumps({"spawn_check": True, "world": world, "rank_sum": float(t.item()),
+                          "local_ranks_distinct": True}), flush=True)
+    dist.destroy_process_group()
+
+
+# ------------------------------------------------------------------------------ workload ----
 def w_critico(k, theta, refractory, rasters_dev):
     """extract_lsm_features.py:33-60 on the first <=500 clips (device reduction, host scalar)."""
+    import torch
     sub = rasters_dev[:500]
     if sub.numel() == 0 or k == 0:
         return 0.007
@@ -58,25 +114,28 @@ def w_critico(k, theta, refractory, rasters_dev):
 
 
 def make_audio(kind, n, seed):
+    import numpy as np
     from lsm_speech_classifier_amd import synth
     if kind == "white_noise":
         return synth.white_noise(n, seed=seed)
     return synth.class_chirps(np.arange(n) % 12, seed=seed)
 
 
-def cpu_baseline(cfg, audio, res, seconds_budget=20.0):
-    """C oracle (oracle/, kind 'port') on a bounded sample: one clip at a time on one core, like
-    the reference's serial loops (create_dataset.py:143, extract_lsm_features.py:78); then the
-    same sample with one clip per core."""
+def cpu_baseline(cfg, audio, res, seconds_budget=24.0):
+    """C oracle (oracle/, kind 'port') on a bounded sample of the same workload: (1) one clip at a time on
+    one core, like the reference's serial loops (create_dataset.py:143, extract_lsm_features.py:78);
+    (2) the same path on every host core, MEASURED: front end and reservoir each with one clip per OpenMP
+    thread."""
+    import numpy as np
     from lsm_speech_classifier_amd import frontend
     from oracle import cport, ref_numpy
     cport.build()
     coefs = ref_numpy.gammatone_coefs(16000, cfg["n_filters"], 50)
+    thr, gap = frontend.SPIKE_THRESHOLDS, frontend.HYSTERESIS_GAP
 
     def front(a):
         return cport.encode_hysteresis(cport.normalise_resize(cport.gammatone_db(
-            cport.gammatone_spec(a, coefs, 400, 160, 98))), frontend.SPIKE_THRESHOLDS,
-            frontend.HYSTERESIS_GAP)
+            cport.gammatone_spec(a, coefs, 400, 160, 98))), thr, gap)
 
     def one(a):
         return cport.lif_run(res, front(a), FEATURE_SET, want_spikes=False)[0]
@@ -85,48 +144,35 @@ def cpu_baseline(cfg, audio, res, seconds_budget=20.0):
     t0 = time.perf_counter()
     one(audio[1 % len(audio)])
     per_clip = time.perf_counter() - t0
-    n = int(max(2, min(len(audio), seconds_budget / 2 / max(per_clip, 1e-4))))
+    n = int(max(2, min(len(audio), seconds_budget / 3 / max(per_clip, 1e-4))))
     t0 = time.perf_counter()
     for a in audio[:n]:
         one(a)
     t_serial = time.perf_counter() - t0
     cores = os.cpu_count() or 1
-    rasters = np.stack([front(a) for a in audio[:n]])
+    # all cores: enough clips to give every core work for about a third of the budget
+    n_all = int(max(n, min(len(audio), cores * max(1, round(seconds_budget / 3 / max(per_clip, 1e-4))))))
+    t0 = time.perf_counter()
+    rasters = cport.gammatone_frontend_batch(audio[:n_all], coefs, 400, 160, 98, thr, gap, n_threads=cores)
+    t_front_all = time.perf_counter() - t0
     t0 = time.perf_counter()
     cport.lif_run_batch(res, rasters, FEATURE_SET, n_threads=cores)
     t_lif_all = time.perf_counter() - t0
-    t1 = time.perf_counter()
-    for a in audio[:8]:
-        front(a)
-    t_front = (time.perf_counter() - t1) / min(8, len(audio))
     return {
         "value": round(n / t_serial, 3), "unit": "clips/s", "cores": 1, "kind": "port",
         "sample": f"{n} clips of the same workload, C oracle (gather-form LIF + gammatone), one clip "
-                  f"at a time on one core; front end {t_front * 1e3:.1f} ms/clip",
-        "all_cores": {"value": round(n / (t_lif_all + n * t_front / cores), 3), "cores": cores,
-                      "note": "reservoir with one clip per OpenMP thread; front-end time divided by cores"},
+                  f"at a time on one core",
+        "all_cores": {"value": round(n_all / (t_front_all + t_lif_all), 3), "cores": cores,
+                      "sample": f"{n_all} clips, measured: front end {t_front_all:.2f} s + reservoir "
+                                f"{t_lif_all:.2f} s, one clip per OpenMP thread in both"},
     }
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=12)
-    ap.add_argument("--config", default="cfg2", choices=sorted(CONFIGS))
-    ap.add_argument("--batch", type=int, default=0, help="clips per GPU (0 = the config's)")
-    ap.add_argument("--waves-per-clip", type=int, default=0)
-    ap.add_argument("--stage", default="full", choices=["full", "reservoir", "frontend"])
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--from-host", action="store_true",
-                    help="every step first copies its audio batch from pinned host memory (PCIe-inclusive "
-                         "rate; never the contract's `value`, which is quoted on HBM-resident inputs)")
-    ap.add_argument("--streams", type=int, default=6,
-                    help="HIP streams the steps rotate over (consecutive steps overlap; 1 = serial)")
-    ap.add_argument("--pipeline", default="rotate", choices=["rotate", "split"],
-                    help="rotate: whole steps round-robin over --streams streams; split: one stream for "
-                         "the front end, one for the reservoir, linked by events")
-    args = ap.parse_args()
+def run_rank(args):
+    import lsm_speech_classifier_amd                # noqa: F401  (sets GPU_MAX_HW_QUEUES before HIP initialises)
+    from lsm_speech_classifier_amd import pipeline  # noqa: F401
+    import numpy as np
+    import torch
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -134,6 +180,9 @@ def main():
     # LSM_BENCH_FORCE_DIST=1 takes the distributed code path (process group, broadcast, gather,
     # barrier) even with one rank: a rehearsal of the RCCL calls on a 1-GPU box
     use_dist = world > 1 or os.environ.get("LSM_BENCH_FORCE_DIST") == "1"
+    if world != args.gpus and rank == 0:
+        print(f"bench.py: --gpus {args.gpus} but the launcher started {world} rank(s); timing {world}",
+              file=sys.stderr)
     if use_dist:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_PORT", "29531")
@@ -151,10 +200,10 @@ def main():
             dist.init_process_group(backend)
     else:
         torch.cuda.set_device(0)
-    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
     dev = torch.device("cuda", local_rank if use_dist else 0)
 
     from lsm_speech_classifier_amd import frontend, reservoir, snn
+    from lsm_speech_classifier_amd.pipeline import HotPath, DEFAULT_STREAMS
     cfg = CONFIGS[args.config]
     B = args.batch or cfg["batch"]
     fe = frontend.SpikeFrontEnd(cfg["n_filters"], cfg["filterbank"], device=dev)
@@ -172,93 +221,44 @@ def main():
                                         small_world_graph_k=cfg["k"], mean_weight=wc * MULTIPLIER)
     res = reservoir.build_reservoir(params, fe.n_channels)
     net = snn.SNN(params, reservoir=res, device=dev)
+    net.set_kernel(args.kernel)
     n_feat = len(FEATURE_SET) * cfg["n_out"]
-    # Layout of a clip in the reservoir kernel.  The library's own choice (8 waves per clip at B = 256)
-    # minimises the duration of a lone launch; inside the overlapped pipeline, which is bound by vector-ALU
-    # issue, 4 waves per clip (4 neurons per lane) spend fewer instructions on per-wave overheads and the
-    # whole pipeline is 3.5 % faster in a same-box A/B (exp/combo_sweep.sh).
-    if args.waves_per_clip == 0 and max(1, args.streams) > 1 and cfg["N"] <= 1024 and args.stage == "full":
-        args.waves_per_clip = 4
-    lay = net.layout(B, fe.n_steps, args.waves_per_clip)
 
-    ev_pairs = []
-    n_streams = max(1, args.streams)
-    streams = [torch.cuda.Stream(device=dev) for _ in range(n_streams)] if n_streams > 1 else [None]
-    step_no = [0]
+    n_streams = args.streams or DEFAULT_STREAMS
+    hp = HotPath(fe, net, FEATURE_SET, streams=n_streams, waves_per_clip=args.waves_per_clip,
+                 time_reservoir=True)
+    lay = net.layout(B, fe.n_steps, hp.waves_per_clip)
     audio_pinned = torch.from_numpy(audio_np).pin_memory() if args.from_host else None
-    h2d_bufs = [torch.empty_like(audio) for _ in range(n_streams)] if args.from_host else None
     # one gather buffer per stream of the rotation: overlapping steps never share an output
     gather_bufs = ([torch.empty((world * B, n_feat), dtype=torch.float32, device=dev)
-                    for _ in range(n_streams)] if use_dist else None)
+                    for _ in range(hp.n_streams)] if use_dist else None)
 
-    split = args.pipeline == "split" and args.stage == "full" and n_streams > 1
-
-    def step(timed):
-        """One pass of the hot path over the batch, issued on the next stream of the rotation: the
-        work of a step is ordered on its own stream, consecutive steps overlap on the GPU."""
-        if split:
-            return split_step(timed)
-        st = streams[step_no[0] % n_streams]
-        step_no[0] += 1
-        if st is None:
-            return one_step(timed)
-        with torch.cuda.stream(st):
-            return one_step(timed)
-
-    def split_step(timed):
-        """Front end of every step on streams[0], reservoir of every step on streams[1]; the
-        reservoir of step s waits (event) for the front end of step s only."""
-        s_fe, s_lif = streams[0], streams[1]
-        with torch.cuda.stream(s_fe):
-            rasters = fe.encode(audio)
-            ready = torch.cuda.Event()
-            ready.record()
-        rasters.record_stream(s_lif)
-        with torch.cuda.stream(s_lif):
-            s_lif.wait_event(ready)
-            if timed:
+    def step():
+        """One pass of the hot path over the batch on the next stream of the rotation."""
+        slot = hp._step % hp.n_streams
+        if args.stage == "frontend":
+            st = hp.streams[slot]
+            hp._step += 1
+            with torch.cuda.stream(st) if st is not None else torch.cuda.stream(torch.cuda.current_stream()):
+                return fe.encode(audio)
+        if args.stage == "reservoir":
+            st = hp.streams[slot]
+            hp._step += 1
+            with torch.cuda.stream(st) if st is not None else torch.cuda.stream(torch.cuda.current_stream()):
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
-            feats, _, _ = net.run_batch(rasters, FEATURE_SET, waves_per_clip=args.waves_per_clip)
-            if timed:
+                feats, _, _ = net.run_batch(rasters0, FEATURE_SET, waves_per_clip=hp.waves_per_clip)
                 e1.record()
-                ev_pairs.append((e0, e1))
-            if use_dist:
-                step_no[0] += 1
-                gathered = gather_bufs[step_no[0] % n_streams]
-                gather(gathered, feats)
-                return gathered
-            return feats
-
-    def one_step(timed):
-        if args.stage == "reservoir":
-            rasters = rasters0
-        else:
-            src = audio
-            if args.from_host:                      # asynchronous H2D on this step's stream, own buffer
-                src = h2d_bufs[(step_no[0] - 1) % n_streams] if n_streams > 1 else h2d_bufs[0]
-                src.copy_(audio_pinned, non_blocking=True)
-            rasters = fe.encode(src)
-        if args.stage == "frontend":
-            return rasters
-        if timed:
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-        feats, _, _ = net.run_batch(rasters, FEATURE_SET, waves_per_clip=args.waves_per_clip)
-        if timed:
-            e1.record()
-            ev_pairs.append((e0, e1))
+                hp.reservoir_events.append((e0, e1))
+                return feats
+        feats, st = hp.submit(audio_pinned if args.from_host else audio)
         if use_dist:
-            gathered = gather_bufs[(step_no[0] - 1) % n_streams]
-            gather(gathered, feats)
-            return gathered
+            # RCCL's stream is ordered after this step's reservoir kernel and the step's stream after the
+            # gather; with >= 12 hardware queues the exchange does not disturb the other steps in flight
+            with torch.cuda.stream(st):
+                dist.all_gather_into_tensor(gather_bufs[slot], feats)
+            return gather_bufs[slot]
         return feats
-
-    def gather(dst, src):
-        # RCCL's stream is ordered after this step's reservoir kernel and the step's stream after the
-        # gather; with >= 12 hardware queues the exchange does not disturb the other steps in flight
-        # (single-rank rehearsal: 0.785 ms per step with the gather, 0.77 without; exp/dist_rehearsal.sh)
-        dist.all_gather_into_tensor(dst, src)
 
     def fence():
         torch.cuda.synchronize()
@@ -266,15 +266,14 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    for st in streams:                 # inputs were produced on the default stream
-        if st is not None:
-            st.wait_stream(torch.cuda.current_stream())
+    hp.fork_from_current()             # inputs were produced on the default stream
     for _ in range(args.warmup):
-        out = step(False)
+        out = step()
     fence()
+    hp.reservoir_events.clear()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        out = step(True)
+        out = step()
     host_enqueue_ms = (time.perf_counter() - t0) / args.steps * 1e3      # host side of a step (asynchronous)
     fence()
     elapsed = time.perf_counter() - t0
@@ -282,52 +281,34 @@ def main():
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+    ev_pairs = list(hp.reservoir_events)
 
-    # outside the timed region: the reservoir kernel alone on an otherwise idle GPU (for reference
-    # next to the in-region average, which includes sharing the chip with the overlapped steps)
-    fe_ms = None
-    if args.stage != "reservoir" and rank == 0:
-        pairs = []
-        for _ in range(5):
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    def median_ms(fn, reps=5):
+        times = []
+        for _ in range(reps):
+            a0, a1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             torch.cuda.synchronize()
-            e0.record()
-            fe.encode(audio)
-            e1.record()
+            a0.record()
+            fn()
+            a1.record()
             torch.cuda.synchronize()
-            pairs.append(e0.elapsed_time(e1))
-        fe_ms = sorted(pairs)[len(pairs) // 2]
-    serial_ms = None
-    lone_ms = None
-    if args.stage != "frontend" and rank == 0:
-        def lone_launch(wpc):
-            times = []
-            for _ in range(5):
-                a0, a1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                torch.cuda.synchronize()
-                a0.record()
-                net.run_batch(rasters0, FEATURE_SET, waves_per_clip=wpc)
-                a1.record()
-                torch.cuda.synchronize()
-                times.append(a0.elapsed_time(a1))
-            return sorted(times)[len(times) // 2]
-        # the library's own layout for a lone launch (8 waves per clip at B = 256), for reference
-        lone_ms = lone_launch(0)
-        pairs = []
-        for _ in range(5):
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            torch.cuda.synchronize()
-            e0.record()
-            net.run_batch(rasters0, FEATURE_SET, waves_per_clip=args.waves_per_clip)
-            e1.record()
-            torch.cuda.synchronize()
-            pairs.append(e0.elapsed_time(e1))
-        serial_ms = sorted(pairs)[len(pairs) // 2]
+            times.append(a0.elapsed_time(a1))
+        return sorted(times)[len(times) // 2]
+
+    # outside the timed region, on an otherwise idle GPU: the front end alone, the reservoir launch in the
+    # pipeline's layout, and a lone launch in the layout the library picks for that
+    fe_ms = gt_ms = serial_ms = lone_ms = None
+    if rank == 0 and args.stage != "reservoir":
+        fe_ms = median_ms(lambda: fe.encode(audio))
+        if cfg["filterbank"] == "gammatone":
+            gt_ms = median_ms(lambda: fe.spectrogram_db(audio))
+    if rank == 0 and args.stage != "frontend":
+        lone_ms = median_ms(lambda: net.run_batch(rasters0, FEATURE_SET, waves_per_clip=0))
+        serial_ms = median_ms(lambda: net.run_batch(rasters0, FEATURE_SET, waves_per_clip=hp.waves_per_clip))
 
     spikes_per_clip = None
     if args.stage != "frontend":
-        fl = out[:B].float()
-        spikes_per_clip = float(fl[:, :cfg["n_out"]].sum(dim=1).mean())
+        spikes_per_clip = float(out[:B].float()[:, :cfg["n_out"]].sum(dim=1).mean())
 
     if rank == 0:
         ms_step = elapsed / args.steps * 1e3
@@ -343,11 +324,12 @@ def main():
                        "clips_per_gpu": B, "n_filters": cfg["n_filters"], "num_neurons": cfg["N"],
                        "small_world_k": cfg["k"], "num_output_neurons": cfg["n_out"],
                        "time_steps": fe.n_steps, "feature_set": "original",
+                       "reservoir_kernel": net.kernel_in_use(),
                        "waves_per_clip": lay["waves_per_clip"], "lds_bytes_per_clip": lay["lds_bytes"],
                        "inputs": "pinned host memory, copied every step" if args.from_host else "resident in HBM",
                        "host_enqueue_ms_per_step": round(host_enqueue_ms, 4),
-                       "streams": n_streams, "hw_queues": int(os.environ["GPU_MAX_HW_QUEUES"]),
-                       "pipeline": args.pipeline if n_streams > 1 else "serial",
+                       "streams": hp.n_streams, "hw_queues": hp.hw_queues,
+                       "pipeline": "pipeline.HotPath: steps rotate over the streams" if hp.n_streams > 1 else "serial",
                        "mean_output_spikes_per_clip": spikes_per_clip,
                        "sharding": f"clips x{world}, feature all-gather" if world > 1 else "single GPU"},
         }
@@ -357,22 +339,18 @@ def main():
             per_clip = fe.n_channels * fe.n_steps + n_feat * 4 + fe.n_steps * w_bytes / B
             compulsory = fe.n_channels * fe.n_steps + n_feat * 4 + w_bytes / B
             achieved = per_clip * B / (lif_ms * 1e-3) / 1e9
+            kname = {"dense": "lif_dense_kernel", "ring": "lif_ring_kernel", "sparse": "lif_kernel"}[net.kernel_in_use()]
             traffic = None
             tfile = os.path.join(ROOT, "profiles", "lif_traffic.json")
             if os.path.exists(tfile):
-                traffic = json.load(open(tfile)).get(f"{args.config}_B{B}")
+                traffic = json.load(open(tfile)).get(f"{args.config}_B{B}_{net.kernel_in_use()}")
             line["roofline"] = {
-                "bound": "hbm", "kernel": "lif_dense_kernel" if cfg["N"] <= 8192 else "lif_kernel", "achieved": round(achieved, 2),
+                "bound": "hbm", "kernel": kname, "achieved": round(achieved, 2),
                 "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
                 "traffic": traffic, "kernel_ms": round(lif_ms, 4),
-                # the measured memory-side bytes over the duration of the launch they were measured on (a lone
-                # launch, one stream): what the kernel really pulls through the memory side of L2
-                "traffic_gbs": None if (traffic is None or serial_ms is None) else
-                round(traffic / (serial_ms * 1e-3) / 1e9, 1),
-                "traffic_frac_of_peak": None if (traffic is None or serial_ms is None) else
-                round(traffic / (serial_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                 "bytes_per_clip": round(per_clip, 1),
                 "variant": "streamed (C*T + 4*F_feat + T*|W|/B, SURVEY.md 8d); |W| = 8 B x nnz",
+                "traffic_over_algorithmic": None if traffic is None else round(traffic / (per_clip * B), 3),
                 "compulsory_bytes_per_clip": round(compulsory, 1),
                 "compulsory_gbs": round(compulsory * B / (lif_ms * 1e-3) / 1e9, 3),
                 "kernel_clips_per_s": round(B / (lif_ms * 1e-3), 1),
@@ -387,28 +365,37 @@ def main():
                 "idle_gpu_frac": None if serial_ms is None else
                 round(per_clip * B / (serial_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
             }
-        if fe_ms is not None and cfg["filterbank"] == "gammatone":
-            # front end alone on an idle GPU: float64 VALU-issue bound (36 instructions per sample and
-            # channel, none of them fusable into FMAs without changing the rounding), not HBM bound
-            ops = 36.0 * ((fe.ncols - 1) * fe.hop + fe.nwin) * cfg["n_filters"] * B
-            gt_waves = -(-cfg["n_filters"] // 64) * B
-            line["frontend"] = {
-                "kernels": "gammatone_kernel + spec_to_spikes_kernel", "idle_gpu_ms": round(fe_ms, 4),
-                "bound": "valu_f64", "achieved_tflops": round(ops / (fe_ms * 1e-3) / 1e12, 2),
-                "peak_tflops_fma_counted": 78.6, "peak_tops_unfused": 39.3,
-                # the same instruction count over the measured step time of the whole (overlapped) pipeline:
-                # how much of the chip's f64 issue rate the benchmark as a whole sustains
-                "pipeline_tops": round(ops / (ms_step * 1e-3) / 1e12, 2),
-                "pipeline_frac_of_unfused_peak": round(ops / (ms_step * 1e-3) / 1e12 / 39.3, 4),
-                "note": "one float64 operation per lane and instruction (no FMA contraction allowed): the "
-                        "ceiling for this instruction mix is 39.3 Tops/s with all 1024 SIMDs busy and >= 4 "
-                        f"waves per SIMD (exp/ubench_f64.hip); this launch has {gt_waves} waves",
-            }
+            if gt_ms is not None:
+                # the kernel that takes most of the GPU time is the float64 filterbank, bound by vector-ALU issue:
+                # 36 instructions per sample and channel, none fusable into FMAs without changing the rounding
+                ops = 36.0 * ((fe.ncols - 1) * fe.hop + fe.nwin) * cfg["n_filters"] * B
+                line["roofline"]["dominant_kernel_by_time"] = {
+                    "kernel": "gammatone_kernel", "bound": "valu_f64",
+                    "idle_gpu_ms": round(gt_ms, 4), "frontend_idle_gpu_ms": round(fe_ms, 4),
+                    "achieved": round(ops / (gt_ms * 1e-3) / 1e12, 2), "peak": F64_UNFUSED_PEAK_TOPS,
+                    "unit": "T f64 instr-lanes/s", "frac": round(ops / (gt_ms * 1e-3) / 1e12 / F64_UNFUSED_PEAK_TOPS, 4),
+                    "pipeline_achieved": round(ops / (ms_step * 1e-3) / 1e12, 2),
+                    "pipeline_frac": round(ops / (ms_step * 1e-3) / 1e12 / F64_UNFUSED_PEAK_TOPS, 4),
+                    "waves": -(-cfg["n_filters"] // 64) * B,
+                    "note": "peak = one float64 operation per lane and instruction on all 1024 SIMDs with >= 4 waves "
+                            "each (78.6 TFLOPS counts an FMA as two); idle_gpu = the kernel alone, pipeline = the same "
+                            "instruction count over the measured step time of the whole overlapped path",
+                }
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(cfg, audio_np, res)
         print(json.dumps(line), flush=True)
     if use_dist:
         dist.destroy_process_group()
+
+
+def main():
+    args = parse_args()
+    launched = "RANK" in os.environ and "WORLD_SIZE" in os.environ
+    if args.gpus > 1 and not launched:
+        sys.exit(spawn_ranks(args.gpus))            # the parent never touches the GPU
+    if os.environ.get("LSM_BENCH_SPAWN_ONLY") == "1" and launched:
+        return spawn_check()
+    run_rank(args)
 
 
 if __name__ == "__main__":

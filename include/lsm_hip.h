@@ -13,7 +13,8 @@
  *     caller (e.g. torch.Tensor.data_ptr()); tables named coefs / thr_* / key_ids and every
  *     argument of lsm_reservoir_create are HOST memory, copied during the call;
  *   - every launch function takes a hipStream_t as `void *stream` and is asynchronous on it;
- *     none of them allocates, frees or synchronises (safe under hipGraph capture);
+ *     none of them allocates, frees or synchronises, and after a kernel's first use its launch is the
+ *     only runtime call made (safe under hipGraph capture: tests/test_gpu_graph.py);
  *   - the only device memory the library owns is inside an lsm_reservoir handle;
  *   - no global mutable state: distinct handles/streams may be used from distinct threads.
  */
@@ -117,11 +118,14 @@ int lsm_reservoir_create(lsm_reservoir **out, int num_neurons, int n_channels,
 int lsm_reservoir_destroy(lsm_reservoir *h);
 
 /* Kernel used by lsm_reservoir_run for this handle: 0 = choose (register accumulation over dense
- * presynaptic rows; over band rows -- dense ring window + list of the synapses outside it -- for ring-like
- * reservoirs whose dense table exceeds the Infinity Cache), 1 = sparse CSC scatter through LDS, 2 = dense rows, 3 = band rows
- * (refused when the reservoir is not ring-like).  All produce bit-identical results (SPEC.md §3).
- * num_neurons <= 8192. */
+ * presynaptic rows; over ring rows -- dense ring window + list of the synapses outside it -- for ring-like
+ * reservoirs whose dense table exceeds the L2 caches), 1 = sparse CSC scatter through LDS, 2 = dense rows,
+ * 3 = ring rows (refused when the reservoir is not ring-like or has fewer than ~700 neurons).  All produce
+ * bit-identical results (SPEC.md §3).  num_neurons <= 8192. */
 int lsm_reservoir_set_kernel(lsm_reservoir *h, int mode);
+
+/* The kernel lsm_reservoir_run would launch for this handle now: 1 sparse, 2 dense rows, 3 ring rows. */
+int lsm_reservoir_kernel_in_use(const lsm_reservoir *h);
 
 /* Replaces, for a whole batch, the per-clip loop body of extract_all_features
  * (extract_lsm_features.py:78-87): reset -> set_input_spike_times -> simulate ->
@@ -133,11 +137,15 @@ int lsm_reservoir_set_kernel(lsm_reservoir *h, int mode);
  *   features_out     (n_clips, n_keys*n_out) float32, device
  *   spike_matrix_out (n_clips, n_steps, N) uint8 or NULL   (lsm.spike_matrix, :113-116)
  *   v_trace_out      (n_clips, n_steps, N) float32 or NULL (membrane potential after each step)
- *   waves_per_clip   0 = choose from the batch size; else 1, 2, 4, 8 or 16 */
+ *   stats_out        (n_clips, 2) int32 or NULL: per clip {neurons that fired at least once, spikes of the
+ *                    whole reservoir} -- what run_network_diagnostics (:119-133) derives from lsm.spike_matrix
+ *                    (participation, dead neurons, mean spikes per neuron), accumulated inside the kernel
+ *   waves_per_clip   0 = choose for a lone launch of this batch size; -1 = choose for a launch that shares
+ *                    the GPU with other kernels of an overlapped pipeline; else 1, 2, 4, 8 or 16 */
 int lsm_reservoir_run(const lsm_reservoir *h, const uint8_t *spikes_u8, int n_clips, int n_steps,
                       const int32_t *key_ids, int n_keys, float *features_out,
-                      uint8_t *spike_matrix_out, float *v_trace_out, int waves_per_clip,
-                      void *stream);
+                      uint8_t *spike_matrix_out, float *v_trace_out, int32_t *stats_out,
+                      int waves_per_clip, void *stream);
 
 /* Layout that lsm_reservoir_run would use: waves per clip, 64-neuron slots per lane, LDS bytes. */
 int lsm_reservoir_layout(const lsm_reservoir *h, int n_clips, int n_steps, int waves_per_clip,

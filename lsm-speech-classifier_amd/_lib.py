@@ -34,8 +34,9 @@ _SIGS = {
                                      c_void, c_int, c_float, c_void, c_int, c_float, c_int, c_int]),
     "lsm_reservoir_destroy": (c_int, [c_void]),
     "lsm_reservoir_set_kernel": (c_int, [c_void, c_int]),
+    "lsm_reservoir_kernel_in_use": (c_int, [c_void]),
     "lsm_reservoir_run": (c_int, [c_void, c_void, c_int, c_int, c_void, c_int, c_void, c_void,
-                                  c_void, c_int, c_void]),
+                                  c_void, c_void, c_int, c_void]),
     "lsm_reservoir_layout": (c_int, [c_void, c_int, c_int, c_int, C.POINTER(c_int),
                                      C.POINTER(c_int), C.POINTER(c_int)]),
     "lsm_debug_lif_stamps": (c_int, [c_void, c_int]),

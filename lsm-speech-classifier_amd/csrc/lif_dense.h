@@ -38,17 +38,12 @@ struct DenseArgs {
     const int *oslot;          // (NPAD) output slot or -1
     const uint32_t *in_ent;    // (WPC, EinW) (channel << 16) | target, 0xFFFFFFFF = padding
     const uint32_t *inmask;    // (NPAD, 4) input-channel bit mask per neuron (INMODE 2: C <= 128), or null
-    // band rows (BAND): row j holds the weights onto the ring window of targets j-band_h .. j+band_h
-    // (circular, dense, band_ld floats per row); the synapses outside the window sit in rem, rem_e slots of
-    // {target local to the owning wave, weight bits} per (row, wave) of this layout, padded with 0xFFFFFFFF
-    const float *band;
-    const uint2 *rem;
-    int band_ld, band_h, rem_e;
     int n_keys;
     int key_ids[8];
     float *features;           // (B, n_keys * n_out)
     uint8_t *spike_matrix;     // (B, T, N) or null
     float *v_trace;            // (B, T, N) or null
+    int32_t *stats;            // (B, 2) {neurons that fired at least once, spikes of the whole reservoir} or null
 };
 
 // INMODE: how the input drive m_i(t) = #{active channels feeding neuron i} is formed.
@@ -57,14 +52,8 @@ struct DenseArgs {
 //   2  every neuron holds the bit mask of its input channels in registers (C <= 128, SL <= 4) and counts
 //      popcount(mask & row) against the step's wave-uniform input bit row: no atomics, no count array,
 //      and nothing to wait for between the recurrent rows and the update
-// BAND: the reservoir is a small-world graph -- a ring lattice with a few rewired edges -- so about 90 % of a
-// row's synapses fall into the ring window around j.  The row is then a dense WINDOW (2*band_h+1 floats, read
-// only by the waves whose targets it touches) plus a short list of the rewired synapses per (row, wave); the
-// list entries are delivered to the lanes that own the targets through the wave's (otherwise idle) count
-// array in LDS.  A target gets row j's weight either from the window or from the list, never both, and rows
-// are still applied in ascending j, so every target's float32 sum keeps the oracle's order.  6-10 KB per row
-// instead of 16-32 KB: the large reservoirs are bound by the bytes of the row gathers.
-template <int SL, int WPC, int INMODE, bool BAND = false>
+// (Ring-like reservoirs whose dense table no longer fits the caches run on lif_ring.h instead: window + list rows.)
+template <int SL, int WPC, int INMODE>
 __global__ __launch_bounds__(WPC * 64) void lif_dense_kernel(const DenseArgs a)
 {
     constexpr bool INREG = INMODE == 1;
@@ -159,6 +148,8 @@ __global__ __launch_bounds__(WPC * 64) void lif_dense_kernel(const DenseArgs a)
     const char *wt_bytes = reinterpret_cast<const char *>(a.wt);
     const uint32_t ld_bytes = (uint32_t)a.ld * 4u;
     const uint32_t lane_off = (uint32_t)(w * NPW + lane) * 4u;
+    uint32_t hf = 0u;                  // bit r: my neuron r fired at least once (stats)
+    uint32_t tot_spk = 0u;             // spikes of my wave (stats)
     __syncthreads();
 
     // input drive of step `ts`: count the active channels feeding each target (integer atomics)
@@ -221,33 +212,12 @@ __global__ __launch_bounds__(WPC * 64) void lif_dense_kernel(const DenseArgs a)
             while (todo != 0ull) {
                 const int n8 = min((int)__builtin_popcountll(todo), G);
                 float wv[16][SL];                   // only the first G rows are ever live
-                uint2 re[16];                       // BAND: my list entry of each row in flight
 #define LSM_LD(k)                                                                   \
     {                                                                               \
         const int sk = __builtin_ctzll(todo);                                       \
         todo &= todo - 1ull;                                                        \
         const uint32_t j = __builtin_amdgcn_readlane(jl, sk);                       \
-        if (BAND) {                                                                 \
-            /* window start (may be negative) and whether my wave's targets meet the window */ \
-            const int sj = (int)j - a.band_h;                                       \
-            const int wd = 2 * a.band_h + 1;                                        \
-            int d0 = w * NPW - sj;                                                  \
-            d0 = d0 < 0 ? d0 + N : (d0 >= N ? d0 - N : d0);                         \
-            const bool meets = d0 < wd || N - d0 < NPW;                             \
-            const float *brow = a.band + (size_t)j * a.band_ld;                     \
-            _Pragma("unroll") for (int r = 0; r < SL; ++r) {                        \
-                float v = 0.0f;                                                     \
-                if (meets) {                                                        \
-                    const int tg = (w * SL + r) * 64 + lane;                        \
-                    int q = tg - sj;                                                \
-                    q = q < 0 ? q + N : (q >= N ? q - N : q);                       \
-                    if (tg < N && q < wd) v = brow[q];                              \
-                }                                                                   \
-                wv[k][r] = v;                                                       \
-            }                                                                       \
-            re[k] = lane < a.rem_e ? a.rem[((size_t)j * WPC + w) * a.rem_e + lane]  \
-                                   : make_uint2(0xFFFFFFFFu, 0u);                   \
-        } else {                                                                    \
+        {                                                                           \
             const char *rowp = wt_bytes + (((LSM_ABLATE & 32) ? (j & 255u) : j) * ld_bytes); \
             _Pragma("unroll") for (int r = 0; r < SL; ++r)                          \
                 wv[k][r] = (LSM_ABLATE & 16) ? __uint_as_float(j + r)               \
@@ -272,29 +242,13 @@ __global__ __launch_bounds__(WPC * 64) void lif_dense_kernel(const DenseArgs a)
                 if (G > 14 && todo) { LSM_LD(14)
                 if (G > 15 && todo) { LSM_LD(15) } } } } } } } } } } } } } } }
 #undef LSM_LD
-                if (!BAND && !drove) {            // the input counts fill the load latency (BAND: the count
-                    input_drive(t);               // array is the delivery scratch until the rows are done)
+                if (!drove) {                     // the input counts fill the load latency
+                    input_drive(t);
                     drove = true;
                 }
 #define LSM_ADD(k)                                                                  \
     {                                                                               \
         _Pragma("unroll") for (int r = 0; r < SL; ++r) cin[r] = cin[r] + wv[k][r];  \
-        if (BAND) {                                                                 \
-            /* rewired synapses of this row onto my wave: park the weights at their targets, every lane */ \
-            /* picks up its own slots (0 where nothing was parked), the parked words are cleared again */ \
-            uint32_t *scr = icnt + w * NPW;                                         \
-            const bool mine = re[k].x != 0xFFFFFFFFu;                               \
-            /* (lanes talk to each other here: the wave-level fences keep the three phases apart --   */ \
-            /*  without them the compiler folds store/load/clear into the branch of the parking lanes) */ \
-            if (mine) scr[re[k].x] = re[k].y;                                       \
-            wave_lds_fence();                                                       \
-            float got[SL];                                                          \
-            _Pragma("unroll") for (int r = 0; r < SL; ++r)                          \
-                got[r] = __uint_as_float(scr[r * 64 + lane]);                       \
-            wave_lds_fence();                                                       \
-            if (mine) scr[re[k].x] = 0u;                                            \
-            _Pragma("unroll") for (int r = 0; r < SL; ++r) cin[r] = cin[r] + got[r]; \
-        }                                                                           \
     }
                 LSM_ADD(0)
                 if (n8 > 1) { LSM_ADD(1)
@@ -385,6 +339,7 @@ __global__ __launch_bounds__(WPC * 64) void lif_dense_kernel(const DenseArgs a)
                     const uint16_t me = (uint16_t)((w * SL + r) * 64 + lane);
                     list_cur[rank] = me;
                     if (rank < R) flist[cur * 64 + w * R + rank] = me;
+                    hf |= 1u << r;
                     if (os[r] >= 0 && !(LSM_ABLATE & 8)) {
                         uint4 f = feat[os[r]];
                         uint32_t n = f.x & 0xFFFFu, bursts = f.x >> 16;
@@ -404,6 +359,7 @@ __global__ __launch_bounds__(WPC * 64) void lif_dense_kernel(const DenseArgs a)
                 nspk += __popcll(bal[r]);
             }
         }
+        tot_spk += (uint32_t)nspk;
         if (lane == 0) wcnt[cur * 16 + w] = (uint32_t)nspk;   // > R: next step's consumers merge the lists
         if (trace) {
 #pragma unroll
@@ -419,7 +375,18 @@ __global__ __launch_bounds__(WPC * 64) void lif_dense_kernel(const DenseArgs a)
         if (!(LSM_ABLATE & 4)) __syncthreads();
     }
 
-    // ---- epilogue: SPEC.md §4 features from the integer accumulators (float64, then float32) ----
+    // ---- epilogue: health statistics (/root/reference/extract_lsm_features.py:119-133 derives them from the
+    //      (T, N) spike matrix; here they come from one flag per neuron and one count per wave), then
+    //      SPEC.md §4 features from the integer accumulators (float64, then float32) ----
+    if (a.stats) {
+        atomicAdd(&wcnt[32], (uint32_t)__popc(hf));
+        if (lane == 0) atomicAdd(&wcnt[33], tot_spk);
+        __syncthreads();
+        if (tid == 0) {
+            a.stats[2 * b] = (int32_t)wcnt[32];
+            a.stats[2 * b + 1] = (int32_t)wcnt[33];
+        }
+    }
     const int nf = a.n_keys * a.n_out;
     for (int idx = tid; idx < nf; idx += NT) {
         const int kq = idx / a.n_out;
@@ -449,28 +416,28 @@ __global__ __launch_bounds__(WPC * 64) void lif_dense_kernel(const DenseArgs a)
 
 typedef void (*dense_fn_t)(const DenseArgs);
 
-template <int SL, int INMODE, bool BAND>
+template <int SL, int INMODE>
 dense_fn_t pick_dense_wpc(int wpc)
 {
     switch (wpc) {
-    case 1: return lif_dense_kernel<SL, 1, INMODE, BAND>;
-    case 2: return lif_dense_kernel<SL, 2, INMODE, BAND>;
-    case 4: return lif_dense_kernel<SL, 4, INMODE, BAND>;
-    case 8: return lif_dense_kernel<SL, 8, INMODE, BAND>;
-    case 16: return lif_dense_kernel<SL, 16, INMODE, BAND>;
+    case 1: return lif_dense_kernel<SL, 1, INMODE>;
+    case 2: return lif_dense_kernel<SL, 2, INMODE>;
+    case 4: return lif_dense_kernel<SL, 4, INMODE>;
+    case 8: return lif_dense_kernel<SL, 8, INMODE>;
+    case 16: return lif_dense_kernel<SL, 16, INMODE>;
     default: return nullptr;
     }
 }
 
-template <int INMODE, bool BAND = false>
+template <int INMODE>
 dense_fn_t pick_dense_sl(int sl, int wpc)
 {
     switch (sl) {
-    case 1: return pick_dense_wpc<1, INMODE, BAND>(wpc);
-    case 2: return pick_dense_wpc<2, INMODE, BAND>(wpc);
-    case 4: return pick_dense_wpc<4, INMODE, BAND>(wpc);
-    case 8: if (INMODE == 2) return nullptr; else return pick_dense_wpc<INMODE == 2 ? 4 : 8, INMODE, BAND>(wpc);
-    case 16: if (INMODE == 2) return nullptr; else return pick_dense_wpc<INMODE == 2 ? 4 : 16, INMODE, BAND>(wpc);
+    case 1: return pick_dense_wpc<1, INMODE>(wpc);
+    case 2: return pick_dense_wpc<2, INMODE>(wpc);
+    case 4: return pick_dense_wpc<4, INMODE>(wpc);
+    case 8: if (INMODE == 2) return nullptr; else return pick_dense_wpc<INMODE == 2 ? 4 : 8, INMODE>(wpc);
+    case 16: if (INMODE == 2) return nullptr; else return pick_dense_wpc<INMODE == 2 ? 4 : 16, INMODE>(wpc);
     default: return nullptr;
     }
 }
@@ -478,8 +445,5 @@ dense_fn_t pick_dense_sl(int sl, int wpc)
 dense_fn_t pick_dense_0(int sl, int wpc);      // lif_dense_0.hip (INMODE 0: entries from global memory)
 dense_fn_t pick_dense_1(int sl, int wpc);      // lif_dense_1.hip (INMODE 1: entries in registers)
 dense_fn_t pick_dense_2(int sl, int wpc);      // lif_dense_2.hip (INMODE 2: channel masks, C <= 128, SL <= 4)
-dense_fn_t pick_band_0(int sl, int wpc);       // lif_band_{0,1,2}.hip: the same on band rows + rewired lists
-dense_fn_t pick_band_1(int sl, int wpc);
-dense_fn_t pick_band_2(int sl, int wpc);
 
 }  // namespace lsm_lif

@@ -76,6 +76,7 @@ struct LifArgs {
     float *features;           // (B, n_keys * n_out)
     uint8_t *spike_matrix;     // (B, T, N) or null
     float *v_trace;            // (B, T, N) or null
+    int32_t *stats;            // (B, 2) {neurons that fired at least once, spikes of the whole reservoir} or null
 };
 
 __device__ __forceinline__ void wave_lds_fence()
@@ -185,6 +186,8 @@ __global__ __launch_bounds__(WPC * 64) void lif_kernel(const LifArgs a)
     const float theta = a.theta, w_in = a.w_in;
     const uint32_t *my_ent = a.in_ent + (size_t)w * a.EinW;   // !INREG: streamed from L2 each step
     const bool trace = a.spike_matrix != nullptr || a.v_trace != nullptr;
+    uint32_t hf = 0u;                  // bit r: my neuron r fired at least once (stats)
+    uint32_t tot_spk = 0u;             // spikes of my wave (stats)
     __syncthreads();
 
     // input drive of step `ts`: count the active channels feeding each target (integer atomics,
@@ -364,6 +367,7 @@ __global__ __launch_bounds__(WPC * 64) void lif_kernel(const LifArgs a)
                 const bool fire = (bal[r] >> lane) & 1ull;
                 if (fire) {
                     list_cur[nspk + lane_rank(bal[r])] = (uint16_t)((w * SL + r) * 64 + lane);
+                    hf |= 1u << r;
                     if (os[r] >= 0) {
                         uint4 f = feat[os[r]];
                         uint32_t n = f.x & 0xFFFFu, bursts = f.x >> 16;
@@ -383,6 +387,7 @@ __global__ __launch_bounds__(WPC * 64) void lif_kernel(const LifArgs a)
                 nspk += __popcll(bal[r]);
             }
         }
+        tot_spk += (uint32_t)nspk;
         if (lane == 0) wcnt[cur * 16 + w] = (uint32_t)nspk;
         if (trace) {
 #pragma unroll
@@ -406,7 +411,17 @@ __global__ __launch_bounds__(WPC * 64) void lif_kernel(const LifArgs a)
         for (int k = 0; k < 8; ++k) atomicAdd(&g_lif_stamps[k], st_sum[k]);
 #endif
 
-    // ---- epilogue: SPEC.md §4 features from the integer accumulators (float64, then float32) ----
+    // ---- epilogue: health statistics (the count array is idle and all zero after the last step), then
+    //      SPEC.md §4 features from the integer accumulators (float64, then float32) ----
+    if (a.stats) {
+        atomicAdd(&icnt[0], (uint32_t)__popc(hf));
+        if (lane == 0) atomicAdd(&icnt[1], tot_spk);
+        __syncthreads();
+        if (tid == 0) {
+            a.stats[2 * b] = (int32_t)icnt[0];
+            a.stats[2 * b + 1] = (int32_t)icnt[1];
+        }
+    }
     const int nf = a.n_keys * a.n_out;
     for (int idx = tid; idx < nf; idx += NT) {
         const int kq = idx / a.n_out;

@@ -1,0 +1,500 @@
+// lif_ring.h -- LIF reservoir time loop on RING rows (small-world reservoirs, N up to 8192), gfx950.
+//
+// Same contract as lif_kernel.h / lif_dense.h (SPEC.md §3-§4; replaces reset / set_input_spike_times /
+// simulate / extract_features_from_spikes of /root/reference/extract_lsm_features.py:79-83), third data
+// structure.  The dense-row kernel moves N*4 bytes per spiking neuron and clip, 80 % of them zeros; at
+// N >= 4000 that is what bounds it (profiles/r01_big_traffic.json: 8-17x the algorithmic bytes).  A
+// Watts-Strogatz reservoir is a ring lattice with ~10 % rewired edges, so row j is stored as
+//   * its ring WINDOW: the weights onto the targets from the 256-aligned start of j-H .. j+H (circular),
+//     dense, in natural target order, 16-byte granules -- fetched with bounds-checked 16-byte buffer loads:
+//     a lane owns FOUR consecutive neurons of a 256-neuron "quad", a wave QL quads, and a quad the window
+//     does not reach is an out-of-range load that returns zeros without touching memory, so every wave runs
+//     the same straight-line code for every row (no per-slot index arithmetic, no branches);
+//   * a LIST of the synapses outside the window ("rewired"), per (row, wave), unpadded: {LDS byte offset of
+//     the target's scratch word, weight bits}.  One lane per entry PARKS the weight in the wave's scratch
+//     array, every lane reads back its own SL words (16-byte LDS reads), the parked words are cleared
+//     again.  LDS executes a wave's instructions in order, so park / read / clear need no waits between
+//     them, and idle lanes park into a 64-word dump region instead of being masked off.
+// A target receives row j's weight from the window or from the list, never both, the other term is +0.0
+// (x + 0 = x in float32 for every x the sum can take), and rows are applied in ascending j: every target's
+// float32 sum keeps the oracle's order and is bit-identical.
+//
+// Rows are pipelined: P rows' loads are in flight while the oldest is applied, so the Infinity-Cache / HBM
+// latency of the row gathers overlaps the LDS hand-off and the register adds of the rows before it.
+#pragma once
+#include "lif_kernel.h"
+
+namespace lsm_lif {
+
+// a += b on four floats.  LSM_RING_SCALAR_ADD: four v_add_f32 instead of two v_pk_add_f32 (experiment switch)
+#if defined(LSM_RING_SCALAR_ADD)
+#define LSM_RING_ADD4(a, b)                                                          \
+    {                                                                                \
+        float _x = a.x, _y = a.y, _z = a.z, _w = a.w;                                \
+        asm volatile("v_add_f32 %0, %0, %1" : "+v"(_x) : "v"(b.x));                  \
+        asm volatile("v_add_f32 %0, %0, %1" : "+v"(_y) : "v"(b.y));                  \
+        asm volatile("v_add_f32 %0, %0, %1" : "+v"(_z) : "v"(b.z));                  \
+        asm volatile("v_add_f32 %0, %0, %1" : "+v"(_w) : "v"(b.w));                  \
+        a = (ring_f4){_x, _y, _z, _w};                                               \
+    }
+#else
+#define LSM_RING_ADD4(a, b) a = a + b;
+#endif
+
+#ifndef LSM_RING_ABLATE
+#define LSM_RING_ABLATE 0   // diagnostic builds only (1, 2, 8 give WRONG results): 1 = no window loads, 2 = no LDS
+#endif                      // hand-off, 4 = window adds only for rows that reach my quads (exact), 8 = no list loads
+
+struct RingArgs {
+    int N, C, T, B;
+    int n_out, CW, EinW, refractory, burst_isi_max;
+    int H;                     // ring half-width (window = targets j-H .. j+H, circular)
+    int NQ;                    // quads holding real neurons: ceil(N / 256)
+    uint32_t pitch;            // bytes between consecutive band rows
+    float theta, w_in;
+    const uint8_t *raster;     // (B, C, T) uint8
+    const float *band;         // (N, pitch/4): window of row j, quad-aligned start, natural target order
+    const uint32_t *rem_ptr;   // (N*WPC + 1) first list entry of (row j, wave w)
+    const uint2 *rem;          // list entries {LDS byte offset of the target's scratch word, weight bits}
+    const float *leak;         // (NPAD), neuron order
+    const int *oslot;          // (NPAD) output slot or -1, neuron order
+    const uint32_t *in_ent;    // (WPC, EinW) (channel << 16) | scratch WORD index of the target, 0xFFFFFFFF = padding
+    int n_keys;
+    int key_ids[8];
+    float *features;           // (B, n_keys * n_out)
+    uint8_t *spike_matrix;     // (B, T, N) or null
+    float *v_trace;            // (B, T, N) or null
+    int32_t *stats;            // (B, 2) {neurons that fired at least once, spikes of the whole reservoir} or null
+};
+
+typedef float ring_f4 __attribute__((ext_vector_type(4)));
+typedef uint32_t ring_u4 __attribute__((ext_vector_type(4)));
+typedef uint32_t ring_u2 __attribute__((ext_vector_type(2)));
+
+constexpr int RING_DUMP_WORDS = 64;                 // LDS words 0..63: where idle lanes park
+__host__ __device__ constexpr int ring_stride(int sl) { return sl == 4 ? 4 : sl + 4; }   // scratch words per lane:
+                                                    // 16-byte reads of 16 lanes then fall on 16 distinct 4-bank groups
+
+// scratch WORD index (from the start of LDS) of neuron i in the layout (QL quads per wave)
+__host__ __device__ inline int ring_scr_word(int i, int ql)
+{
+    const int sl = 4 * ql, npw = sl * 64;
+    const int w = i / npw, rem = i - w * npw;
+    const int q = rem >> 8, lane = (rem & 255) >> 2, h = rem & 3;
+    return RING_DUMP_WORDS + (w * 64 + lane) * ring_stride(sl) + q * 4 + h;
+}
+
+// QL: quads (256 neurons, 4 per lane) per wave; WPC: waves per clip; INREG: the wave's input-map entries sit
+// in registers (else they stream from global memory every step).
+template <int QL, int WPC, bool INREG>
+__global__ __launch_bounds__(WPC * 64) void lif_ring_kernel(const RingArgs a)
+{
+    constexpr int SL = 4 * QL;
+    constexpr int NPW = SL * 64;
+    constexpr int NPAD = NPW * WPC;
+    constexpr int NT = WPC * 64;
+    constexpr int STRIDE = ring_stride(SL);
+    constexpr int P = QL >= 4 ? 4 : 8;              // rows in flight (QL*4 + 2 registers each)
+    constexpr uint32_t RSRC_FLAGS = 0x00020000u;    // raw dword buffer, gfx9 family
+
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    uint32_t *scr = reinterpret_cast<uint32_t *>(smem);                               // dump + WPC*64*STRIDE
+    uint16_t *wlist = reinterpret_cast<uint16_t *>(scr + RING_DUMP_WORDS + WPC * 64 * STRIDE);   // 2*NPAD
+    uint32_t *wcnt = reinterpret_cast<uint32_t *>(wlist + 2 * NPAD);                  // 2*16 counts + 2 stats
+    uint4 *feat = reinterpret_cast<uint4 *>(wcnt + 64);                               // n_out
+    uint32_t *bits = reinterpret_cast<uint32_t *>(feat + a.n_out);                    // T*CW
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int b = blockIdx.x;
+    const int N = a.N, T = a.T, CW = a.CW;
+
+    // ---- prologue: zero LDS state, bit-pack the clip's raster time-major ----
+    for (int i = tid; i < RING_DUMP_WORDS + WPC * 64 * STRIDE; i += NT) scr[i] = 0u;
+    if (tid < 64) wcnt[tid] = 0u;
+    for (int i = tid; i < a.n_out; i += NT) feat[i] = make_uint4(0, 0, 0, 0);
+    for (int i = tid; i < T * CW; i += NT) bits[i] = 0u;
+    __syncthreads();
+    {
+        const uint8_t *clip = a.raster + (size_t)b * a.C * T;
+        if ((T & 3) == 0) {
+            const uint32_t *clip4 = reinterpret_cast<const uint32_t *>(clip);
+            const int nd = a.C * T / 4;
+            for (int q = tid; q < nd; q += NT) {
+                const uint32_t v = clip4[q];
+                if (v == 0) continue;
+                const int c = (q * 4) / T;
+                const int t0 = (q * 4) - c * T;
+                const uint32_t bit = 1u << (c & 31);
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    if ((v >> (8 * k)) & 0xFFu) atomicOr(&bits[(t0 + k) * CW + (c >> 5)], bit);
+            }
+        } else {
+            const int nb = a.C * T;
+            for (int q = tid; q < nb; q += NT)
+                if (clip[q]) {
+                    const int c = q / T;
+                    atomicOr(&bits[(q - c * T) * CW + (c >> 5)], 1u << (c & 31));
+                }
+        }
+    }
+
+    // my neurons: register r = 4*q + h  <->  neuron (w*QL + q)*256 + lane*4 + h
+    // oref[r] = (output slot + 1) | (refractory countdown << 16): one register for both, "held" is one
+    // unsigned compare, the slot is unpacked only when the neuron fires.
+    float v[SL], lam[SL];
+    uint32_t oref[SL];
+#pragma unroll
+    for (int q = 0; q < QL; ++q) {
+        const int i0 = (w * QL + q) * 256 + lane * 4;
+        const float4 l4 = *reinterpret_cast<const float4 *>(a.leak + i0);
+        const int4 o4 = *reinterpret_cast<const int4 *>(a.oslot + i0);
+        const float l[4] = {l4.x, l4.y, l4.z, l4.w};
+        const int o[4] = {o4.x, o4.y, o4.z, o4.w};
+#pragma unroll
+        for (int h = 0; h < 4; ++h) {
+            v[4 * q + h] = 0.0f;
+            // padding neurons (i >= N) get a NaN leak: their potential is NaN from the first step on, the
+            // threshold test is false for ever -- a window that wraps past the ring's end may deliver weights
+            // of real quads to them, and they must never fire
+            lam[4 * q + h] = (i0 + h) < N ? l[h] : __builtin_nanf("");
+            oref[4 * q + h] = (uint32_t)(o[h] + 1);
+        }
+    }
+    const uint32_t ref_set = (uint32_t)a.refractory << 16;
+    uint32_t in_word[IN_REG_SLOTS], in_mask[IN_REG_SLOTS], in_tgt[IN_REG_SLOTS];
+    if (INREG) {
+#pragma unroll
+        for (int q = 0; q < IN_REG_SLOTS; ++q) {
+            const int e = q * 64 + lane;
+            const uint32_t x = e < a.EinW ? a.in_ent[(size_t)w * a.EinW + e] : 0xFFFFFFFFu;
+            const bool ok = x != 0xFFFFFFFFu;
+            const uint32_t c = x >> 16;
+            in_word[q] = ok ? (c >> 5) : 0u;
+            in_mask[q] = ok ? (1u << (c & 31)) : 0u;
+            in_tgt[q] = ok ? (x & 0xFFFFu) : (uint32_t)lane;          // padding: own dump word, adds 0
+        }
+    }
+    const float theta = a.theta, w_in = a.w_in;
+    const uint32_t *my_ent = a.in_ent + (size_t)w * a.EinW;
+    const bool trace = a.spike_matrix != nullptr || a.v_trace != nullptr;
+    uint32_t *myscr = scr + RING_DUMP_WORDS + (w * 64 + lane) * STRIDE;      // my SL scratch words
+    const uint32_t lane4 = (uint32_t)lane * 4u, lane8 = (uint32_t)lane * 8u, lane16 = (uint32_t)lane * 16u;
+    const uint64_t band_base = reinterpret_cast<uint64_t>(a.band);
+    const uint64_t rem_base = reinterpret_cast<uint64_t>(a.rem);
+    const int H = a.H, NQ = a.NQ;
+    uint32_t hf = 0u;                  // bit r: my neuron r fired at least once (stats)
+    uint32_t tot_spk = 0u;             // spikes of my wave (stats)
+    __syncthreads();
+
+    auto input_drive = [&](int ts) {
+        const uint32_t *row = bits + ts * CW;
+        if (INREG) {
+#pragma unroll
+            for (int q = 0; q < IN_REG_SLOTS; q += 2) {
+                if (q * 64 < a.EinW) {
+                    const uint32_t w0 = row[in_word[q]], w1 = row[in_word[q + 1]];
+                    atomicAdd(scr + in_tgt[q], (w0 & in_mask[q]) ? 1u : 0u);
+                    if ((q + 1) * 64 < a.EinW) atomicAdd(scr + in_tgt[q + 1], (w1 & in_mask[q + 1]) ? 1u : 0u);
+                }
+            }
+        } else {
+            // eight entries per lane are fetched together (one L2 round trip per 512 entries instead of one per
+            // 64); a padding entry counts 0 into the lane's own dump word, so nothing is masked off
+            for (int e0 = 0; e0 < a.EinW; e0 += 512) {
+                uint32_t x[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int e = e0 + u * 64 + lane;
+                    x[u] = e < a.EinW ? my_ent[e] : 0xFFFFFFFFu;
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    if (e0 + u * 64 < a.EinW) {                     // wave-uniform
+                        const bool ok = x[u] != 0xFFFFFFFFu;
+                        const uint32_t c = ok ? (x[u] >> 16) : 0u;
+                        const uint32_t bit = (row[c >> 5] >> (c & 31)) & 1u;
+                        atomicAdd(scr + (ok ? (x[u] & 0xFFFFu) : (uint32_t)lane), ok ? bit : 0u);
+                    }
+                }
+            }
+        }
+    };
+
+    for (int t = 0; t < T; ++t) {
+        const int cur = t & 1, prv = cur ^ 1;
+        const uint16_t *list_prev = wlist + prv * NPAD;
+        uint16_t *list_cur = wlist + cur * NPAD + w * NPW;
+
+        ring_f4 cin[QL];
+#pragma unroll
+        for (int q = 0; q < QL; ++q) cin[q] = (ring_f4){0.0f, 0.0f, 0.0f, 0.0f};
+
+        // ---- spiking neurons of step t-1: prefix of the per-wave counts, lane l <- l-th neuron ----
+        const uint32_t cv = wcnt[prv * 16 + (lane & 15)];
+        uint32_t total = 0u;
+#pragma unroll
+        for (int q = 0; q < WPC; ++q) total += __builtin_amdgcn_readlane(cv, q);
+
+        for (uint32_t l0 = 0; l0 < total; l0 += 64) {
+            const uint32_t l = l0 + lane;
+            uint32_t wsel = 0u, pbase = 0u, run = 0u;      // (the prefix is formed again per chunk: it would
+#pragma unroll                                             //  otherwise hold WPC scalar registers across the rows)
+            for (int q = 1; q < WPC; ++q) {
+                run += __builtin_amdgcn_readlane(cv, q - 1);
+                const bool ge = l >= run;
+                wsel += ge ? 1u : 0u;
+                pbase = ge ? run : pbase;
+            }
+            const bool valid = l < total;
+            const int jl = valid ? (int)list_prev[wsel * NPW + (l - pbase)] : 0;
+            // ---- lane l: everything a wave needs to fetch row jl, computed for 64 rows at once ----
+            // window = targets from the 256-aligned start of jl-H up to jl+H (circular in N); in the stored row
+            // quad (q0 + p) mod NQ sits at position p.  Bytes of the row that exist: up to the window's end.
+            int a0 = jl - H; a0 += a0 < 0 ? N : 0;
+            int b0 = jl + H; b0 -= b0 >= N ? N : 0;
+            const int q0 = a0 >> 8, q1 = b0 >> 8;
+            int p1 = q1 - q0; p1 += p1 < 0 ? NQ : 0;
+            const uint32_t p_nrec = valid ? (uint32_t)(p1 * 1024 + (((b0 & 255) >> 2) + 1) * 16) : 0u;
+            // position of my wave's first quad in that row: quads below q0 sit NQ further (wrapped window); a
+            // wave never holds both ends of a window (host: window quads + QL <= NQ)
+            const int g0 = w * QL;
+            const int base = (g0 + QL - 1 < q0) ? g0 - q0 + NQ : g0 - q0;
+            const uint32_t p_soff = (uint32_t)(base * 1024);            // negative: wraps to > any num_records
+            // rows whose window reaches none of my quads (two thirds of them at 8 waves per clip): their
+            // window loads run with one active lane and their window adds are skipped
+            const unsigned long long inmask = __ballot(valid && base + QL > 0 && base <= p1);
+            const uint64_t baddr = band_base + (uint64_t)(uint32_t)jl * a.pitch;
+            const uint32_t p_blo = (uint32_t)baddr, p_bhi = (uint32_t)(baddr >> 32);
+            uint32_t r0 = 0u, r1 = 0u;
+            if (valid) {
+                r0 = a.rem_ptr[jl * WPC + w];
+                r1 = a.rem_ptr[jl * WPC + w + 1];
+            }
+            const uint64_t raddr = rem_base + (uint64_t)r0 * 8u;
+            const uint32_t p_rlo = (uint32_t)raddr, p_rhi = (uint32_t)(raddr >> 32);
+            const uint32_t p_rnrec = (r1 - r0) * 8u;
+            const int n = (int)min(64u, total - l0);
+
+            ring_f4 wv[P][QL];
+            ring_u2 re[P];
+            ring_f4 got[2][QL];
+            bool iw[P];                          // buffer p holds a row whose window reaches my quads
+            // LOAD(p, m): issue the loads of the chunk's row m (a scalar) into buffer p.  Rows >= n do not
+            // exist: their num_records is 0, every load is out of range and returns zeros without traffic.
+#define LSM_RING_LOAD(p, m)                                                                     \
+    {                                                                                           \
+        const int mm = (m) & 63;                                                                \
+        const uint32_t live = (uint32_t) - (int)((m) < n);                                      \
+        const uint32_t blo = __builtin_amdgcn_readlane(p_blo, mm);                              \
+        const uint32_t bhi = __builtin_amdgcn_readlane(p_bhi, mm);                              \
+        const uint32_t nrec = __builtin_amdgcn_readlane(p_nrec, mm) & live;                     \
+        const uint32_t soff = __builtin_amdgcn_readlane(p_soff, mm);                            \
+        const uint32_t rlo = __builtin_amdgcn_readlane(p_rlo, mm);                              \
+        const uint32_t rhi = __builtin_amdgcn_readlane(p_rhi, mm);                              \
+        const uint32_t rnrec = __builtin_amdgcn_readlane(p_rnrec, mm) & live;                   \
+        const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc(                    \
+            reinterpret_cast<void *>(((uint64_t)bhi << 32) | blo), 0, (int)nrec, RSRC_FLAGS);   \
+        iw[p] = ((inmask >> mm) & 1ull) != 0ull && (m) < n;                                     \
+        _Pragma("unroll") for (int q = 0; q < QL; ++q) {                                        \
+            /* the whole byte offset goes through the VGPR (opaque scalar: nothing is folded into the    */ \
+            /* instruction's immediate), so a quad in front of the window is a huge unsigned offset and  */ \
+            /* out of range whatever the address adder does with a carry                                  */ \
+            uint32_t so = soff + (uint32_t)q * 1024u;                                           \
+            asm volatile("" : "+s"(so));                                                        \
+            if (LSM_RING_ABLATE & 1) {                                                          \
+                wv[p][q] = (ring_f4){0.0f, 0.0f, 0.0f, 0.0f};                                   \
+            } else {                                                                            \
+                const ring_u4 x = __builtin_amdgcn_raw_buffer_load_b128(rb, (int)(lane16 + so), 0, 0); \
+                wv[p][q] = (ring_f4){__uint_as_float(x.x), __uint_as_float(x.y),                \
+                                     __uint_as_float(x.z), __uint_as_float(x.w)};               \
+            }                                                                                   \
+        }                                                                                       \
+        const __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc(                    \
+            reinterpret_cast<void *>(((uint64_t)rhi << 32) | rlo), 0, (int)rnrec, RSRC_FLAGS);  \
+        if (LSM_RING_ABLATE & 8) re[p] = (ring_u2){0u, 0u};                                     \
+        else re[p] = __builtin_amdgcn_raw_buffer_load_b64(rr, (int)lane8, 0, 0);                \
+        __builtin_amdgcn_sched_barrier(0);                                                      \
+    }
+            // PARK(p, g): the rewired synapses of the row in buffer p reach their targets through the scratch
+            // array: park, every lane reads its SL words into got[g], clear -- LDS runs a wave's instructions
+            // in order, so nothing waits in between.  Lanes without an entry got {0, 0} from the bounds check
+            // and park a zero into their own dump word.
+#define LSM_RING_PARK(p, g)                                                                     \
+    {                                                                                           \
+        if (LSM_RING_ABLATE & 2) {                                                              \
+            _Pragma("unroll") for (int q = 0; q < QL; ++q)                                      \
+                got[g][q] = (ring_f4){__uint_as_float(re[p].x), 0.0f, 0.0f, __uint_as_float(re[p].y)}; \
+        } else {                                                                                \
+            const uint32_t pa = max(re[p].x, lane4);                                            \
+            asm volatile("" ::: "memory");                                                      \
+            *reinterpret_cast<uint32_t *>(smem + pa) = re[p].y;                                 \
+            asm volatile("" ::: "memory");                                                      \
+            _Pragma("unroll") for (int q = 0; q < QL; ++q)                                      \
+                got[g][q] = *reinterpret_cast<const ring_f4 *>(myscr + 4 * q);                  \
+            asm volatile("" ::: "memory");                                                      \
+            *reinterpret_cast<uint32_t *>(smem + pa) = 0u;                                      \
+            asm volatile("" ::: "memory");                                                      \
+        }                                                                                       \
+        __builtin_amdgcn_sched_barrier(0);                                                      \
+    }
+            // ADD(p, g): row p's contributions, ascending-j order of the rows = order of these calls
+#define LSM_RING_ADD(p, g)                                                                      \
+    {                                                                                           \
+        _Pragma("unroll") for (int q = 0; q < QL; ++q) LSM_RING_ADD4(cin[q], got[g][q])         \
+        if (!(LSM_RING_ABLATE & 4) || iw[p]) {                                                  \
+            _Pragma("unroll") for (int q = 0; q < QL; ++q) LSM_RING_ADD4(cin[q], wv[p][q])      \
+        }                                                                                       \
+        __builtin_amdgcn_sched_barrier(0);                                                      \
+    }
+            // software pipeline: P rows of loads in flight; the LDS hand-off of row m+1 is issued before the
+            // adds of row m, so its round trip hides behind them
+#pragma unroll
+            for (int p = 0; p < P; ++p) LSM_RING_LOAD(p, p)
+            LSM_RING_PARK(0, 0)
+            for (int m = 0; m < n; m += P) {
+#pragma unroll
+                for (int p = 0; p < P; ++p) {
+                    LSM_RING_PARK((p + 1) % P, (p + 1) & 1)
+                    LSM_RING_ADD(p, p & 1)
+                    LSM_RING_LOAD(p, m + p + P)
+                }
+            }
+#undef LSM_RING_LOAD
+#undef LSM_RING_PARK
+#undef LSM_RING_ADD
+        }
+        input_drive(t);
+        wave_lds_fence();
+
+        // ---- neuron update, quad by quad: leak/integrate/threshold by select, then (only if a neuron of the
+        //      quad fired) its entries of the step's spike list and the feature accumulators ----
+        int nspk = 0;
+#pragma unroll
+        for (int q = 0; q < QL; ++q) {
+            const ring_u4 nin = *reinterpret_cast<const ring_u4 *>(myscr + 4 * q);
+            *reinterpret_cast<ring_u4 *>(myscr + 4 * q) = (ring_u4){0u, 0u, 0u, 0u};
+            const uint32_t nn[4] = {nin.x, nin.y, nin.z, nin.w};
+            float ci[4] = {cin[q].x, cin[q].y, cin[q].z, cin[q].w};
+            unsigned long long bq[4];
+#pragma unroll
+            for (int h = 0; h < 4; ++h) {
+                const int r = 4 * q + h;
+                ci[h] = ci[h] + w_in * (float)nn[h];       // SPEC.md §3: input term after the recurrent sum
+                const bool held = oref[r] >= 0x10000u;
+                const float m = lam[r] * v[r];
+                const float d = v[r] - m;
+                const float vn = d + ci[h];
+                const bool fire = !held && (vn >= theta);
+                v[r] = (held || fire) ? 0.0f : vn;
+                oref[r] += held ? 0xFFFF0000u : (fire ? ref_set : 0u);
+                bq[h] = __ballot(fire);
+            }
+            if ((bq[0] | bq[1] | bq[2] | bq[3]) != 0ull) {
+                // ascending neuron order inside a quad: lane, then h
+                int rank = nspk + lane_rank(bq[0]) + lane_rank(bq[1]) + lane_rank(bq[2]) + lane_rank(bq[3]);
+#pragma unroll
+                for (int h = 0; h < 4; ++h) {
+                    const int r = 4 * q + h;
+                    if ((bq[h] >> lane) & 1ull) {
+                        list_cur[rank] = (uint16_t)((w * QL + q) * 256 + lane * 4 + h);
+                        rank += 1;
+                        hf |= 1u << r;
+                        const int osl = (int)(oref[r] & 0xFFFFu) - 1;
+                        if (osl >= 0) {
+                            uint4 f = feat[osl];
+                            uint32_t nf = f.x & 0xFFFFu, bursts = f.x >> 16;
+                            uint32_t first = f.y & 0xFFFFu, last = f.y >> 16;
+                            const uint32_t isi = (uint32_t)t - last;
+                            first = nf == 0 ? (uint32_t)t : first;
+                            f.w += nf == 0 ? 0u : isi * isi;
+                            bursts += (nf != 0 && (int)isi <= a.burst_isi_max) ? 1u : 0u;
+                            last = (uint32_t)t;
+                            nf += 1;
+                            f.z += (uint32_t)t;
+                            f.x = nf | (bursts << 16);
+                            f.y = first | (last << 16);
+                            feat[osl] = f;
+                        }
+                    }
+                }
+                nspk += __popcll(bq[0]) + __popcll(bq[1]) + __popcll(bq[2]) + __popcll(bq[3]);
+            }
+            if (trace) {
+#pragma unroll
+                for (int h = 0; h < 4; ++h) {
+                    const int i = (w * QL + q) * 256 + lane * 4 + h;
+                    if (i < N) {
+                        if (a.spike_matrix)
+                            a.spike_matrix[((size_t)b * T + t) * N + i] = (uint8_t)((bq[h] >> lane) & 1ull);
+                        if (a.v_trace) a.v_trace[((size_t)b * T + t) * N + i] = v[4 * q + h];
+                    }
+                }
+            }
+        }
+        tot_spk += (uint32_t)nspk;
+        if (lane == 0) wcnt[cur * 16 + w] = (uint32_t)nspk;
+        __syncthreads();
+    }
+
+    // ---- epilogue: health statistics, then SPEC.md §4 features from the integer accumulators ----
+    if (a.stats) {
+        atomicAdd(&wcnt[32], (uint32_t)__popc(hf));
+        if (lane == 0) atomicAdd(&wcnt[33], tot_spk);
+        __syncthreads();
+        if (tid == 0) {
+            a.stats[2 * b] = (int32_t)wcnt[32];
+            a.stats[2 * b + 1] = (int32_t)wcnt[33];
+        }
+    }
+    const int nf = a.n_keys * a.n_out;
+    for (int idx = tid; idx < nf; idx += NT) {
+        const int kq = idx / a.n_out;
+        const int o = idx - kq * a.n_out;
+        const uint4 f = feat[o];
+        const int n = (int)(f.x & 0xFFFFu), bursts = (int)(f.x >> 16);
+        const int first = (int)(f.y & 0xFFFFu), last = (int)(f.y >> 16);
+        double val = 0.0;
+        switch (a.key_ids[kq]) {
+        case 0: val = (double)n; break;
+        case 1: { const double p = (double)n / (double)T; val = p * (1.0 - p); } break;
+        case 2: val = n >= 1 ? (double)f.z / (double)n : 0.0; break;
+        case 3: val = n >= 1 ? (double)first : 0.0; break;
+        case 4: val = n >= 1 ? (double)last : 0.0; break;
+        case 5: val = n >= 2 ? (double)(last - first) / (double)(n - 1) : 0.0; break;
+        case 6:
+            if (n >= 2) {
+                const double m = (double)(last - first) / (double)(n - 1);
+                val = (double)f.w / (double)(n - 1) - m * m;
+            }
+            break;
+        default: val = (double)bursts; break;
+        }
+        a.features[(size_t)b * nf + idx] = (float)val;
+    }
+}
+
+typedef void (*ring_fn_t)(const RingArgs);
+
+template <int QL, bool INREG>
+ring_fn_t pick_ring_wpc(int wpc)
+{
+    switch (wpc) {
+    case 2: return lif_ring_kernel<QL, 2, INREG>;
+    case 4: return lif_ring_kernel<QL, 4, INREG>;
+    case 8: return lif_ring_kernel<QL, 8, INREG>;
+    case 16:
+        if constexpr (QL < 4) return lif_ring_kernel<QL, 16, INREG>;     // N <= 8192 = 16 waves x 2 quads
+        else return nullptr;
+    default: return nullptr;
+    }
+}
+
+// one definition per translation unit lif_ring_<ql>.hip
+ring_fn_t pick_ring_1(int wpc, bool inreg);
+ring_fn_t pick_ring_2(int wpc, bool inreg);
+ring_fn_t pick_ring_4(int wpc, bool inreg);
+
+}  // namespace lsm_lif

@@ -1,0 +1,9 @@
+// Ring-row LIF kernel instantiations with 1 quad(s) (= 4 neurons per lane) per wave (see lif_ring.h).
+#include "lif_ring.h"
+
+namespace lsm_lif {
+ring_fn_t pick_ring_1(int wpc, bool inreg)
+{
+    return inreg ? pick_ring_wpc<1, true>(wpc) : pick_ring_wpc<1, false>(wpc);
+}
+}  // namespace lsm_lif

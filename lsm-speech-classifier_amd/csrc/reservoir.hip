@@ -2,9 +2,13 @@
 // segment tables), layout choice and kernel launch.  The kernel itself lives in lif_kernel.h and
 // is instantiated by the four lif_variant_*.hip translation units.
 #include "lif_dense.h"
+#include "lif_ring.h"
 
 #include <algorithm>
 #include <cstring>
+#include <mutex>
+#include <set>
+#include <utility>
 #include <vector>
 
 using lsm_lif::LifArgs;
@@ -43,9 +47,27 @@ struct Variant {            // per waves-per-clip layout
     int *oslot = nullptr;
     uint32_t *in_ent = nullptr;
     uint32_t *inmask = nullptr;      // (npad, 4) input-channel masks, only when C <= 128 and sl <= 4
-    uint2 *rem = nullptr;            // band format: (N, wpc, rem_e) synapses outside the ring window
-    int rem_e = 0;                   // 0: this layout has no band format (a list would exceed 64 entries)
 };
+
+struct RingVariant {        // per waves-per-clip layout of the ring-row kernel (lif_ring.h)
+    int wpc = 0, ql = 0, einw = 0;
+    uint32_t *rem_ptr = nullptr;     // (N*wpc + 1) first list entry of (row, wave)
+    uint2 *rem = nullptr;            // synapses outside the ring window: {LDS byte offset, weight bits}
+    float *leak = nullptr;
+    int *oslot = nullptr;
+    uint32_t *in_ent = nullptr;      // (wpc, einw) (channel << 16) | scratch word index
+};
+
+// Kernels that need more than 64 KB of dynamic LDS must raise the limit once per function and device; doing
+// it at launch time would put an API call that is not a launch into every call (and into graph captures).
+void allow_big_lds(const void *fn, int device)
+{
+    static std::mutex mu;
+    static std::set<std::pair<const void *, int>> done;
+    std::lock_guard<std::mutex> lk(mu);
+    if (done.insert({fn, device}).second)
+        (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+}
 
 }  // namespace
 
@@ -58,11 +80,14 @@ struct lsm_reservoir {
     uint32_t *rowptr = nullptr;
     float *wt = nullptr;    // dense rows by presynaptic neuron (N, ld), small reservoirs only
     int ld = 0;
-    // band format (lif_dense.h, BAND): dense ring window of 2*band_h+1 targets per presynaptic neuron
+    // ring rows (lif_ring.h): per presynaptic neuron the dense ring window from the 256-aligned start of
+    // j-H up to j+H, plus per-layout lists of the synapses outside it
     float *band = nullptr;
-    int band_ld = 0, band_h = 0;
-    int mode = 0;           // 0 auto, 1 sparse (CSC scatter through LDS), 2 dense rows, 3 band rows
+    uint32_t band_pitch = 0;
+    int band_h = 0, band_nq = 0, band_wsq = 0;
+    int mode = 0;           // 0 auto, 1 sparse (CSC scatter through LDS), 2 dense rows, 3 ring rows
     Variant var[5];         // wpc = 1, 2, 4, 8, 16 (wpc == 0: not available)
+    RingVariant rvar[4];    // wpc = 2, 4, 8, 16
 };
 
 static int free_reservoir(lsm_reservoir *h)
@@ -79,7 +104,13 @@ static int free_reservoir(lsm_reservoir *h)
         if (v.oslot) (void)hipFree(v.oslot);
         if (v.in_ent) (void)hipFree(v.in_ent);
         if (v.inmask) (void)hipFree(v.inmask);
+    }
+    for (auto &v : h->rvar) {
+        if (v.rem_ptr) (void)hipFree(v.rem_ptr);
         if (v.rem) (void)hipFree(v.rem);
+        if (v.leak) (void)hipFree(v.leak);
+        if (v.oslot) (void)hipFree(v.oslot);
+        if (v.in_ent) (void)hipFree(v.in_ent);
     }
     delete h;
     return LSM_OK;
@@ -224,11 +255,14 @@ int lsm_reservoir_create(lsm_reservoir **out, int num_neurons, int n_channels,
         if ((rc = upload(&h->wt, wt))) { free_reservoir(h); return rc; }
         h->ld = ldmax;
     }
-    // Band format for ring-like graphs: window half-width = half the mean out-degree (k/2 of a small-world
-    // graph), used when the window is a real saving (< half a row) and holds most of the synapses.
+    // Ring rows for ring-like graphs (lif_ring.h): window half-width H = half the mean out-degree (k/2 of a
+    // small-world graph).  Row j covers the targets from the 256-aligned start of (j-H) mod N up to (j+H) mod N;
+    // quad (q0 + p) mod NQ of the ring sits at position p of the stored row.  Offered when the plain window
+    // holds most of the synapses and is a real saving (< half a row).
     {
         const int H = (int)((nnz / (size_t)N + 1) / 2);
         const int wd = 2 * H + 1;
+        const int NQ = (N + 255) / 256;
         size_t inside = 0;
         for (int j = 0; j < N; ++j)
             for (int e = csc_ptr[j]; e < csc_ptr[j + 1]; ++e) {
@@ -236,45 +270,88 @@ int lsm_reservoir_create(lsm_reservoir **out, int num_neurons, int n_channels,
                 q = q < 0 ? q + N : (q >= N ? q - N : q);
                 inside += q < wd;
             }
-        if (H >= 1 && 2 * wd <= N && nnz > 0 && inside * 10 >= nnz * 6) {
-            const int bld = (wd + 3) / 4 * 4;
-            std::vector<float> band((size_t)N * bld, 0.0f);
-            for (int j = 0; j < N; ++j)
-                for (int e = csc_ptr[j]; e < csc_ptr[j + 1]; ++e) {
-                    int q = csc_post[e] - (j - H);
-                    q = q < 0 ? q + N : (q >= N ? q - N : q);
-                    if (q < wd) band[(size_t)j * bld + q] = csc_w[e];
+        if (H >= 1 && 2 * wd <= N && NQ >= 2 && nnz > 0 && inside * 10 >= nnz * 6) {
+            // geometry per row: q0 (first quad), bytes that exist (up to the window's end, 16-byte granules)
+            std::vector<int> q0v(N), nbytes(N);
+            int wsq = 0;
+            for (int j = 0; j < N; ++j) {
+                int a0 = j - H; a0 += a0 < 0 ? N : 0;
+                int b0 = j + H; b0 -= b0 >= N ? N : 0;
+                const int q0 = a0 >> 8, q1 = b0 >> 8;
+                int p1 = q1 - q0; p1 += p1 < 0 ? NQ : 0;
+                q0v[j] = q0;
+                nbytes[j] = p1 * 1024 + (((b0 & 255) >> 2) + 1) * 16;
+                wsq = std::max(wsq, p1 + 1);
+            }
+            if (wsq < NQ) {
+                const uint32_t pitch = (uint32_t)wsq * 1024u;
+                std::vector<float> band((size_t)N * (pitch / 4), 0.0f);
+                // byte offset of synapse (j -> i) in row j, or -1 when i lies outside the stored window
+                auto win_off = [&](int j, int i) -> long {
+                    int p = (i >> 8) - q0v[j]; p += p < 0 ? NQ : 0;
+                    const long off = (long)p * 1024 + (long)(i & 255) * 4;
+                    return off < nbytes[j] ? off : -1;
+                };
+                for (int j = 0; j < N; ++j)
+                    for (int e = csc_ptr[j]; e < csc_ptr[j + 1]; ++e) {
+                        const long off = win_off(j, csc_post[e]);
+                        if (off >= 0) band[(size_t)j * (pitch / 4) + (size_t)(off / 4)] = csc_w[e];
+                    }
+                if ((rc = upload(&h->band, band))) { free_reservoir(h); return rc; }
+                h->band_pitch = pitch; h->band_h = H; h->band_nq = NQ; h->band_wsq = wsq;
+                const int rwpcs[4] = {2, 4, 8, 16};
+                for (int vi = 0; vi < 4; ++vi) {
+                    const int wpc = rwpcs[vi];
+                    int ql = 0;
+                    for (int cand : {1, 2, 4})
+                        if (!ql && wpc * cand * 256 >= N) ql = cand;
+                    // a wave must never hold both ends of a (wrapped) window: window quads + QL <= NQ
+                    if (!ql || wsq + ql > NQ) continue;
+                    const int npw = ql * 256, npad = npw * wpc;
+                    std::vector<uint32_t> rptr((size_t)N * wpc + 1, 0u);
+                    int emax = 0;
+                    for (int j = 0; j < N; ++j)
+                        for (int e = csc_ptr[j]; e < csc_ptr[j + 1]; ++e)
+                            if (win_off(j, csc_post[e]) < 0)
+                                emax = std::max(emax, (int)++rptr[(size_t)j * wpc + csc_post[e] / npw + 1]);
+                    if (emax > 64) continue;                             // one lane per list entry
+                    for (size_t q = 1; q < rptr.size(); ++q) rptr[q] += rptr[q - 1];
+                    std::vector<uint2> rem(std::max<size_t>(1, rptr.back()));
+                    std::vector<uint32_t> fill(rptr.begin(), rptr.end() - 1);
+                    for (int j = 0; j < N; ++j)
+                        for (int e = csc_ptr[j]; e < csc_ptr[j + 1]; ++e) {
+                            const int i = csc_post[e];
+                            if (win_off(j, i) >= 0) continue;
+                            uint32_t bits;
+                            std::memcpy(&bits, &csc_w[e], 4);
+                            rem[fill[(size_t)j * wpc + i / npw]++] =
+                                make_uint2((uint32_t)lsm_lif::ring_scr_word(i, ql) * 4u, bits);
+                        }
+                    std::vector<float> lk(npad, 0.0f);
+                    std::vector<int> os(npad, -1);
+                    for (int i = 0; i < N; ++i) lk[i] = leak[i];
+                    for (int o = 0; o < n_out; ++o) os[out_idx[o]] = o;
+                    std::vector<std::vector<uint32_t>> per(wpc);
+                    for (int c = 0; c < C; ++c)
+                        for (int d = 0; d < in_fanout; ++d) {
+                            const int tgt = in_tgt[(size_t)c * in_fanout + d];
+                            per[tgt / npw].push_back(((uint32_t)c << 16) |
+                                                     (uint32_t)lsm_lif::ring_scr_word(tgt, ql));
+                        }
+                    size_t mx = 1;
+                    for (auto &pp : per) mx = std::max(mx, pp.size());
+                    const int einw = (int)((mx + 63) / 64 * 64);
+                    std::vector<uint32_t> ent((size_t)wpc * einw, 0xFFFFFFFFu);
+                    for (int w = 0; w < wpc; ++w)
+                        std::copy(per[w].begin(), per[w].end(), ent.begin() + (size_t)w * einw);
+                    RingVariant &v = h->rvar[vi];
+                    if ((rc = upload(&v.rem_ptr, rptr)) || (rc = upload(&v.rem, rem)) || (rc = upload(&v.leak, lk)) ||
+                        (rc = upload(&v.oslot, os)) || (rc = upload(&v.in_ent, ent))) {
+                        free_reservoir(h);
+                        return rc;
+                    }
+                    v.wpc = wpc; v.ql = ql; v.einw = einw;
                 }
-            if ((rc = upload(&h->band, band))) { free_reservoir(h); return rc; }
-            h->band_ld = bld; h->band_h = H;
-            for (auto &v : h->var) {
-                if (!v.wpc) continue;
-                const int npw = v.sl * 64;
-                std::vector<int> cnt((size_t)N * v.wpc, 0);
-                int emax = 0;
-                for (int j = 0; j < N; ++j)
-                    for (int e = csc_ptr[j]; e < csc_ptr[j + 1]; ++e) {
-                        int q = csc_post[e] - (j - H);
-                        q = q < 0 ? q + N : (q >= N ? q - N : q);
-                        if (q >= wd) emax = std::max(emax, ++cnt[(size_t)j * v.wpc + csc_post[e] / npw]);
-                    }
-                const int E = std::max(4, (emax + 3) / 4 * 4);
-                if (E > 64) continue;                         // one lane per entry: not for this layout
-                std::vector<uint2> rem((size_t)N * v.wpc * E, make_uint2(0xFFFFFFFFu, 0u));
-                std::fill(cnt.begin(), cnt.end(), 0);
-                for (int j = 0; j < N; ++j)
-                    for (int e = csc_ptr[j]; e < csc_ptr[j + 1]; ++e) {
-                        int q = csc_post[e] - (j - H);
-                        q = q < 0 ? q + N : (q >= N ? q - N : q);
-                        if (q < wd) continue;
-                        const int wv = csc_post[e] / npw;
-                        uint32_t bits;
-                        std::memcpy(&bits, &csc_w[e], 4);
-                        rem[((size_t)j * v.wpc + wv) * E + cnt[(size_t)j * v.wpc + wv]++] =
-                            make_uint2((uint32_t)(csc_post[e] - wv * npw), bits);
-                    }
-                if ((rc = upload(&v.rem, rem))) { free_reservoir(h); return rc; }
-                v.rem_e = E;
             }
         }
     }
@@ -282,13 +359,20 @@ int lsm_reservoir_create(lsm_reservoir **out, int num_neurons, int n_channels,
     return LSM_OK;
 }
 
-// 0 = choose (dense rows when the table exists), 1 = sparse CSC kernel, 2 = dense-row kernel.
+static bool has_ring(const lsm_reservoir *h)
+{
+    for (const auto &v : h->rvar)
+        if (v.wpc) return true;
+    return false;
+}
+
+// 0 = choose, 1 = sparse CSC kernel, 2 = dense-row kernel, 3 = ring-row kernel.
 extern "C" __attribute__((visibility("default")))
 int lsm_reservoir_set_kernel(lsm_reservoir *h, int mode)
 {
     LSM_REQUIRE(h != nullptr, "lsm_reservoir_set_kernel: null handle");
-    LSM_REQUIRE(mode >= 0 && mode <= 3, "mode must be 0 (auto), 1 (sparse), 2 (dense) or 3 (band)");
-    LSM_REQUIRE(mode != 3 || h->band != nullptr, "this reservoir has no band format (not ring-like enough)");
+    LSM_REQUIRE(mode >= 0 && mode <= 3, "mode must be 0 (auto), 1 (sparse), 2 (dense) or 3 (ring)");
+    LSM_REQUIRE(mode != 3 || has_ring(h), "this reservoir has no ring-row format (not ring-like, or too small)");
     LSM_REQUIRE(mode != 2 || h->wt != nullptr, "this reservoir has no dense row table");
     h->mode = mode;
     return LSM_OK;
@@ -323,15 +407,39 @@ static size_t lif_lds_bytes(const lsm_reservoir *h, const Variant &v, int T)
     return lif_lds_core(h, v, T) + (lif_seg_in_lds(h, v, T) ? lif_seg_bytes(h, v) : 0);
 }
 
-// band rows: on request, or by default when the dense table no longer fits the 256 MB Infinity Cache -- there
-// the row gathers are bound by HBM bytes and the band format's extra instructions pay (N = 8000: 79 vs 102 ms
-// per 512 clips); while the dense table is cache resident it is the faster one (N = 4000: 13 vs 23 ms)
-constexpr size_t BAND_AUTO_MIN_DENSE_BYTES = (size_t)192 << 20;
-static bool want_band(const lsm_reservoir *h)
+static size_t ring_lds_bytes(const lsm_reservoir *h, const RingVariant &v, int T)
 {
-    if (h->band == nullptr) return false;
+    const size_t npad = (size_t)v.ql * 256 * v.wpc;
+    const size_t cw = (size_t)(h->C + 31) / 32;
+    return ((size_t)lsm_lif::RING_DUMP_WORDS + (size_t)v.wpc * 64 * lsm_lif::ring_stride(4 * v.ql)) * 4 +
+           2 * npad * 2 + 256 + (size_t)h->n_out * 16 + (size_t)T * cw * 4;
+}
+
+// Ring layout for a batch: the requested waves per clip, else the layout with the most neurons per lane
+// (fewest per-row and per-wave overheads) that still gives a clip at least 4 waves.
+static const RingVariant *choose_ring(const lsm_reservoir *h, int T, int requested)
+{
+    const RingVariant *best = nullptr;
+    for (const auto &v : h->rvar) {
+        if (!v.wpc || ring_lds_bytes(h, v, T) > 160 * 1024) continue;
+        if (requested > 0) {
+            if (v.wpc == requested) return &v;
+            continue;
+        }
+        if (!best || (best->wpc < 4 && v.wpc >= 4)) best = &v;
+    }
+    return best;
+}
+
+// ring rows: on request, or by default when the dense table no longer fits the XCDs' L2 caches together
+// (32 MB) -- from there on the dense rows are bound by the bytes of the row gathers, of which the ring
+// format moves a quarter (N = 4000: window 3.6 KB + list 0.6 KB against 16 KB per row)
+constexpr size_t RING_AUTO_MIN_DENSE_BYTES = (size_t)32 << 20;
+static bool want_ring(const lsm_reservoir *h)
+{
+    if (!has_ring(h)) return false;
     if (h->mode == 3) return true;
-    return h->mode == 0 && (size_t)h->N * (size_t)h->ld * 4 > BAND_AUTO_MIN_DENSE_BYTES;
+    return h->mode == 0 && (size_t)h->N * (size_t)h->ld * 4 > RING_AUTO_MIN_DENSE_BYTES;
 }
 static bool use_dense(const lsm_reservoir *h) { return h->wt != nullptr && h->mode != 1; }
 
@@ -346,6 +454,9 @@ static size_t dense_lds_bytes(const lsm_reservoir *h, const Variant &v, int T)
 // about 4096 wavefronts in flight (B=256 -> 16, B=512 -> 8) and never fewer than 4 waves per clip
 // (B=4096: 4 waves 9.1 ms, 2 waves 10.6 ms, 1 wave 17.6 ms).  Among the layouts this reservoir
 // supports and whose LDS image fits one CU, take the smallest one at or above that target.
+// requested == -1: the launch runs inside an overlapped pipeline (other kernels share the CUs): the chip is
+// then bound by vector-ALU issue and fewer, fatter waves spend fewer instructions on per-wave overheads
+// (N=1000, B=256: 4 waves per clip 3.5 % faster for the whole pipeline than 8; a lone launch prefers 8).
 static const Variant *choose_variant(const lsm_reservoir *h, int B, int T, int requested)
 {
     // LDS image of the kernel that will run (the dense-row kernel needs less than the sparse one)
@@ -361,7 +472,8 @@ static const Variant *choose_variant(const lsm_reservoir *h, int B, int T, int r
     // dense-row kernel (measured at N=1000, B=256: 4 waves 0.82 ms, 8 waves 0.75 ms, 16 waves 0.81 ms):
     // about 2048 wavefronts; sparse kernel: about 4096
     const long want = use_dense(h) ? 2048 : 4096;
-    while (target < 16 && (long)B * target < want) target <<= 1;
+    if (requested == 0)
+        while (target < 16 && (long)B * target < want) target <<= 1;
     // large reservoirs: more waves per clip keep the per-lane neuron slots (registers, update work per
     // wave) small -- N=4000, B=1024: 4 waves 68 ms, 8 waves 43 ms, 16 waves 26 ms
     const Variant *best = nullptr;
@@ -375,51 +487,74 @@ static const Variant *choose_variant(const lsm_reservoir *h, int B, int T, int r
 extern "C" __attribute__((visibility("default")))
 int lsm_reservoir_run(const lsm_reservoir *h, const uint8_t *spikes_u8, int n_clips, int n_steps,
                       const int32_t *key_ids, int n_keys, float *features_out,
-                      uint8_t *spike_matrix_out, float *v_trace_out, int waves_per_clip,
-                      void *stream)
+                      uint8_t *spike_matrix_out, float *v_trace_out, int32_t *stats_out,
+                      int waves_per_clip, void *stream)
 {
     LSM_REQUIRE(h != nullptr, "lsm_reservoir_run: null handle");
     LSM_REQUIRE(n_clips >= 0 && n_steps >= 1 && n_steps <= 65535, "bad n_clips/n_steps");
     LSM_REQUIRE(n_keys >= 1 && n_keys <= 8 && key_ids, "n_keys must be in [1, 8]");
+    LSM_REQUIRE(waves_per_clip >= -1 && waves_per_clip <= 16, "waves_per_clip must be -1 (pipelined), 0 (choose) or 1..16");
     if (n_clips == 0) return LSM_OK;            // empty batch: nothing to read or write
     LSM_REQUIRE(spikes_u8 && features_out, "null buffer");
-
-    const Variant *v = choose_variant(h, n_clips, n_steps, waves_per_clip);
-    LSM_REQUIRE(v != nullptr, "no reservoir layout for waves_per_clip=%d (N=%d, T=%d)",
-                waves_per_clip, h->N, n_steps);
     int dev_now = -1;
     LSM_CHECK_HIP(hipGetDevice(&dev_now));
     LSM_REQUIRE(dev_now == h->device, "reservoir handle lives on device %d but the current device is %d",
                 h->device, dev_now);
     for (int k = 0; k < n_keys; ++k)
         LSM_REQUIRE(key_ids[k] >= 0 && key_ids[k] < 8, "key id %d out of range", key_ids[k]);
+    const size_t cw = (size_t)(h->C + 31) / 32;
+
+    if (want_ring(h)) {
+        const RingVariant *rv = choose_ring(h, n_steps, waves_per_clip > 0 ? waves_per_clip : 0);
+        LSM_REQUIRE(rv != nullptr, "no ring-row layout for waves_per_clip=%d (N=%d, T=%d)", waves_per_clip, h->N,
+                    n_steps);
+        const bool inreg = rv->einw <= IN_REG_SLOTS * 64;
+        lsm_lif::ring_fn_t rfn = rv->ql == 1   ? lsm_lif::pick_ring_1(rv->wpc, inreg)
+                                 : rv->ql == 2 ? lsm_lif::pick_ring_2(rv->wpc, inreg)
+                                               : lsm_lif::pick_ring_4(rv->wpc, inreg);
+        LSM_REQUIRE(rfn != nullptr, "no ring kernel for QL=%d WPC=%d", rv->ql, rv->wpc);
+        lsm_lif::RingArgs r;
+        r.N = h->N; r.C = h->C; r.T = n_steps; r.B = n_clips;
+        r.n_out = h->n_out; r.CW = (int)cw; r.EinW = rv->einw;
+        r.refractory = h->refractory; r.burst_isi_max = h->burst_isi_max;
+        r.H = h->band_h; r.NQ = h->band_nq; r.pitch = h->band_pitch;
+        r.theta = h->theta; r.w_in = h->w_in;
+        r.raster = spikes_u8; r.band = h->band; r.rem_ptr = rv->rem_ptr; r.rem = rv->rem;
+        r.leak = rv->leak; r.oslot = rv->oslot; r.in_ent = rv->in_ent;
+        r.n_keys = n_keys;
+        for (int k = 0; k < 8; ++k) r.key_ids[k] = k < n_keys ? key_ids[k] : 0;
+        r.features = features_out; r.spike_matrix = spike_matrix_out; r.v_trace = v_trace_out;
+        r.stats = stats_out;
+        const size_t lds = ring_lds_bytes(h, *rv, n_steps);
+        if (lds > 64 * 1024) allow_big_lds(reinterpret_cast<const void *>(rfn), h->device);
+        hipLaunchKernelGGL(rfn, dim3(n_clips), dim3(rv->wpc * 64), lds, (hipStream_t)stream, r);
+        LSM_CHECK_HIP(hipGetLastError());
+        return LSM_OK;
+    }
+    LSM_REQUIRE(h->mode != 3, "no ring-row layout for this reservoir");
+
+    const Variant *v = choose_variant(h, n_clips, n_steps, waves_per_clip);
+    LSM_REQUIRE(v != nullptr, "no reservoir layout for waves_per_clip=%d (N=%d, T=%d)",
+                waves_per_clip, h->N, n_steps);
     if (use_dense(h)) {
-        const bool band = want_band(h) && v->rem_e > 0;
-        LSM_REQUIRE(band || h->mode != 3, "the band format has no list layout for %d waves per clip", v->wpc);
-        lsm_lif::dense_fn_t dfn =
-            band ? (v->inmask       ? lsm_lif::pick_band_2(v->sl, v->wpc)
-                    : lif_inreg(*v) ? lsm_lif::pick_band_1(v->sl, v->wpc)
-                                    : lsm_lif::pick_band_0(v->sl, v->wpc))
-                 : (v->inmask       ? lsm_lif::pick_dense_2(v->sl, v->wpc)
-                    : lif_inreg(*v) ? lsm_lif::pick_dense_1(v->sl, v->wpc)
-                                    : lsm_lif::pick_dense_0(v->sl, v->wpc));
+        lsm_lif::dense_fn_t dfn = v->inmask       ? lsm_lif::pick_dense_2(v->sl, v->wpc)
+                                  : lif_inreg(*v) ? lsm_lif::pick_dense_1(v->sl, v->wpc)
+                                                  : lsm_lif::pick_dense_0(v->sl, v->wpc);
         LSM_REQUIRE(dfn != nullptr, "no dense kernel for SL=%d WPC=%d", v->sl, v->wpc);
         lsm_lif::DenseArgs d;
         d.N = h->N; d.C = h->C; d.T = n_steps; d.B = n_clips;
-        d.n_out = h->n_out; d.CW = (h->C + 31) / 32; d.EinW = v->einw;
+        d.n_out = h->n_out; d.CW = (int)cw; d.EinW = v->einw;
         d.refractory = h->refractory; d.burst_isi_max = h->burst_isi_max; d.ld = h->ld;
         d.theta = h->theta; d.w_in = h->w_in;
         d.raster = spikes_u8; d.wt = h->wt; d.leak = v->leak; d.oslot = v->oslot; d.in_ent = v->in_ent;
         d.inmask = v->inmask;
-        d.band = h->band; d.rem = v->rem; d.band_ld = h->band_ld; d.band_h = h->band_h; d.rem_e = v->rem_e;
         d.n_keys = n_keys;
         for (int k = 0; k < 8; ++k) d.key_ids[k] = k < n_keys ? key_ids[k] : 0;
         d.features = features_out; d.spike_matrix = spike_matrix_out; d.v_trace = v_trace_out;
+        d.stats = stats_out;
         const size_t dlds = dense_lds_bytes(h, *v, n_steps);
         LSM_REQUIRE(dlds <= 160 * 1024, "dense layout needs %zu bytes of LDS", dlds);
-        if (dlds > 64 * 1024)
-            LSM_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(dfn),
-                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)dlds));
+        if (dlds > 64 * 1024) allow_big_lds(reinterpret_cast<const void *>(dfn), h->device);
         hipLaunchKernelGGL(dfn, dim3(n_clips), dim3(v->wpc * 64), dlds, (hipStream_t)stream, d);
         LSM_CHECK_HIP(hipGetLastError());
         return LSM_OK;
@@ -429,24 +564,19 @@ int lsm_reservoir_run(const lsm_reservoir *h, const uint8_t *spikes_u8, int n_cl
 
     LifArgs a;
     a.N = h->N; a.C = h->C; a.T = n_steps; a.B = n_clips;
-    a.n_out = h->n_out; a.CW = (h->C + 31) / 32; a.EinW = v->einw;
+    a.n_out = h->n_out; a.CW = (int)cw; a.EinW = v->einw;
     a.refractory = h->refractory; a.burst_isi_max = h->burst_isi_max;
     a.theta = h->theta; a.w_in = h->w_in;
     a.rowptr = h->rowptr; a.segoff = v->segoff;
     a.raster = spikes_u8; a.seg = v->seg; a.syn = h->syn; a.leak = v->leak; a.oslot = v->oslot;
     a.in_ent = v->in_ent;
     a.n_keys = n_keys;
-    for (int k = 0; k < 8; ++k) a.key_ids[k] = 0;
-    for (int k = 0; k < n_keys; ++k) {
-        LSM_REQUIRE(key_ids[k] >= 0 && key_ids[k] < 8, "key id %d out of range", key_ids[k]);
-        a.key_ids[k] = key_ids[k];
-    }
+    for (int k = 0; k < 8; ++k) a.key_ids[k] = k < n_keys ? key_ids[k] : 0;
     a.features = features_out; a.spike_matrix = spike_matrix_out; a.v_trace = v_trace_out;
+    a.stats = stats_out;
 
     const size_t lds = lif_lds_bytes(h, *v, n_steps);
-    if (lds > 64 * 1024)
-        LSM_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(fn),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    if (lds > 64 * 1024) allow_big_lds(reinterpret_cast<const void *>(fn), h->device);
     hipLaunchKernelGGL(fn, dim3(n_clips), dim3(v->wpc * 64), lds, (hipStream_t)stream, a);
     LSM_CHECK_HIP(hipGetLastError());
     return LSM_OK;
@@ -458,6 +588,14 @@ int lsm_reservoir_layout(const lsm_reservoir *h, int n_clips, int n_steps, int w
                          int *wpc_out, int *slots_out, int *lds_bytes_out)
 {
     LSM_REQUIRE(h != nullptr, "lsm_reservoir_layout: null handle");
+    if (want_ring(h)) {
+        const RingVariant *rv = choose_ring(h, n_steps, waves_per_clip > 0 ? waves_per_clip : 0);
+        LSM_REQUIRE(rv != nullptr, "no ring-row layout for waves_per_clip=%d", waves_per_clip);
+        if (wpc_out) *wpc_out = rv->wpc;
+        if (slots_out) *slots_out = rv->ql * 4;
+        if (lds_bytes_out) *lds_bytes_out = (int)ring_lds_bytes(h, *rv, n_steps);
+        return LSM_OK;
+    }
     const Variant *v = choose_variant(h, n_clips, n_steps, waves_per_clip);
     LSM_REQUIRE(v != nullptr, "no reservoir layout for waves_per_clip=%d", waves_per_clip);
     if (wpc_out) *wpc_out = v->wpc;
@@ -465,6 +603,14 @@ int lsm_reservoir_layout(const lsm_reservoir *h, int n_clips, int n_steps, int w
     if (lds_bytes_out)
         *lds_bytes_out = (int)(use_dense(h) ? dense_lds_bytes(h, *v, n_steps) : lif_lds_bytes(h, *v, n_steps));
     return LSM_OK;
+}
+
+// Which kernel lsm_reservoir_run would launch for this handle: 1 sparse, 2 dense rows, 3 ring rows.
+extern "C" __attribute__((visibility("default")))
+int lsm_reservoir_kernel_in_use(const lsm_reservoir *h)
+{
+    if (h == nullptr) return LSM_ERR_ARG;
+    return want_ring(h) ? 3 : (use_dense(h) ? 2 : 1);
 }
 
 // Diagnostic builds (-DLSM_STAMP=1) only: per-phase cycle sums of the LIF kernel; zeros otherwise.

@@ -74,12 +74,16 @@ class SNN:
 
     # ---- batched path -------------------------------------------------------------------
     def run_batch(self, spikes, feature_keys=None, want_spike_matrix=False, want_v_trace=False,
-                  waves_per_clip: int = 0, packed_time_steps: int = 0):
+                  waves_per_clip: int = 0, packed_time_steps: int = 0, stats_out=None):
         """spikes: uint8 (B, C, T) torch tensor on this device (or NumPy, copied).  Returns
         (features float32 (B, n_keys*N_out) device tensor, spike_matrix or None, v_trace or None);
         NaN entries are already 0 and keys are concatenated in the given order
         (extract_lsm_features.py:85-87).  With ``packed_time_steps=T`` the input is the bit-packed
-        form (B, C, ceil(T/8)) of ``spikefile``: it is uploaded as it is and unpacked on the GPU."""
+        form (B, C, ceil(T/8)) of ``spikefile``: it is uploaded as it is and unpacked on the GPU.
+        ``stats_out``: optional int32 (B, 2) device tensor that receives, per clip, the number of neurons
+        that fired at least once and the spikes of the whole reservoir (accumulated inside the kernel).
+        ``waves_per_clip``: 0 = the library's layout for a lone launch, -1 = its layout for a launch that
+        shares the GPU with other kernels (``pipeline.HotPath``), else 1, 2, 4, 8 or 16."""
         if isinstance(spikes, np.ndarray):
             spikes = torch.from_numpy(np.ascontiguousarray(spikes, dtype=np.uint8))
         spikes = spikes.to(self.device, dtype=torch.uint8).contiguous()
@@ -98,32 +102,44 @@ class SNN:
               if want_spike_matrix else None)
         vt = (torch.empty((B, T, self.num_neurons), dtype=torch.float32, device=self.device)
               if want_v_trace else None)
+        if stats_out is not None and (stats_out.dtype != torch.int32 or tuple(stats_out.shape) != (B, 2)
+                                      or not stats_out.is_contiguous() or stats_out.device != spikes.device):
+            raise ValueError(f"stats_out must be a contiguous int32 ({B}, 2) tensor on {spikes.device}")
         with torch.cuda.device(self.device):
             _lib.check(self.lib.lsm_reservoir_run(
                 self._handle, _dev(spikes), B, T, _host(key_ids), len(keys), _dev(feats), _dev(sm),
-                _dev(vt), int(waves_per_clip), torch.cuda.current_stream().cuda_stream),
+                _dev(vt), _dev(stats_out), int(waves_per_clip), torch.cuda.current_stream().cuda_stream),
                 "lsm_reservoir_run")
         return feats, sm, vt
 
     def diagnostics(self, spikes) -> dict:
         """Batched health statistics (the quantities /root/reference/extract_lsm_features.py:119-133
-        derives per clip from ``lsm.spike_matrix``), reduced on the device: per clip the share of
-        neurons that fired at least once, the number of silent neurons and the mean spikes per neuron."""
-        _, sm, _ = self.run_batch(spikes, ['spike_counts'], want_spike_matrix=True)
-        per_neuron = sm.sum(dim=1, dtype=torch.int32)                    # (B, N)
-        active = (per_neuron > 0).sum(dim=1).cpu().numpy()                # exact integers from here on
-        total = per_neuron.sum(dim=1, dtype=torch.int64).cpu().numpy()
+        derives per clip from ``lsm.spike_matrix``): per clip the share of neurons that fired at least
+        once, the number of silent neurons and the mean spikes per neuron.  The two integers behind them
+        come out of the reservoir kernel itself (one flag per neuron, one count per wave): no (T, N) spike
+        matrix is written or reduced."""
+        B = int(spikes.shape[0])
+        stats = torch.empty((B, 2), dtype=torch.int32, device=self.device)
+        self.run_batch(spikes, ['spike_counts'], stats_out=stats)
+        st = stats.cpu().numpy().astype(np.int64)                        # exact integers from here on
+        active, total = st[:, 0], st[:, 1]
         return {
             "participation": active / self.num_neurons * 100,           # same expression as the reference
             "dead_neurons": self.num_neurons - active,
             "mean_spikes_per_neuron": total / self.num_neurons,
         }
 
+    KERNEL_MODES = {"auto": 0, "sparse": 1, "dense": 2, "ring": 3, "band": 3}    # 'band': round-1 name of 'ring'
+
     def set_kernel(self, mode: str = "auto"):
-        """'auto' (register accumulation over dense presynaptic rows; over band rows for ring-like
-        reservoirs whose dense table exceeds the Infinity Cache), 'sparse' (CSC scatter through LDS), 'dense' or 'band'."""
-        _lib.check(self.lib.lsm_reservoir_set_kernel(
-            self._handle, {"auto": 0, "sparse": 1, "dense": 2, "band": 3}[mode]), "lsm_reservoir_set_kernel")
+        """'auto' (register accumulation over dense presynaptic rows; over ring rows -- dense ring window
+        plus a list of the rewired synapses -- for ring-like reservoirs whose dense table exceeds the L2
+        caches), 'sparse' (CSC scatter through LDS), 'dense' or 'ring'."""
+        _lib.check(self.lib.lsm_reservoir_set_kernel(self._handle, self.KERNEL_MODES[mode]),
+                   "lsm_reservoir_set_kernel")
+
+    def kernel_in_use(self) -> str:
+        return {1: "sparse", 2: "dense", 3: "ring"}[self.lib.lsm_reservoir_kernel_in_use(self._handle)]
 
     def layout(self, n_clips: int, n_steps: int, waves_per_clip: int = 0):
         wpc, sl, lds = C.c_int(), C.c_int(), C.c_int()

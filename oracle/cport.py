@@ -92,6 +92,23 @@ def encode_hysteresis(spec, thresholds, gap):
     return out
 
 
+def gammatone_frontend_batch(audio, coefs, nwin, hop, ncols, thresholds, gap, time_bins=100, n_threads=1):
+    """(n, n_samples) float32 -> (n, F, time_bins*len(thresholds)) uint8: the whole gammatone front end of a
+    batch, one clip per OpenMP thread (the per-clip functions above, chained in C)."""
+    audio = np.ascontiguousarray(audio, dtype=np.float32)
+    coefs = np.ascontiguousarray(coefs, dtype=np.float64)
+    n, L = audio.shape
+    F = coefs.shape[0]
+    on, off = threshold_tables(thresholds, gap, np.float64)
+    out = np.empty((n, F, time_bins * len(on)), dtype=np.uint8)
+    rc = lib().orc_gammatone_frontend_batch(
+        _p(audio, C.c_float), n, L, _p(coefs, C.c_double), F, nwin, hop, ncols, time_bins,
+        _p(on, C.c_double), _p(off, C.c_double), len(on), int(n_threads), _p(out, C.c_uint8))
+    if rc:
+        raise ValueError(f"orc_gammatone_frontend_batch failed: {rc}")
+    return out
+
+
 def _res_args(res):
     return (res.num_neurons, res.n_channels)
 

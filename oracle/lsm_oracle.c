@@ -191,6 +191,37 @@ ORC_API void orc_encode_hysteresis_f32(const float *spec, int n_filters, int n_b
         }
 }
 
+/* The gammatone front end of a whole batch, one clip per OpenMP thread: spectrogram -> dB + floor ->
+ * normalise/resize -> hysteresis encoder, exactly the per-clip calls above in the order
+ * /root/reference/create_dataset.py:148-157 makes them.  Used by bench.py's cpu_baseline to MEASURE the
+ * all-cores front-end rate (and by a test that checks it against the per-clip calls).
+ * rasters: (n_clips, n_filters, time_bins*n_thr) uint8. */
+ORC_API int orc_gammatone_frontend_batch(const float *audio, int n_clips, int n_samples, const double *coefs,
+                                         int n_filters, int nwin, int hop, int ncols, int time_bins,
+                                         const double *thr_on, const double *thr_off, int n_thr,
+                                         int n_threads, uint8_t *rasters)
+{
+    int bad = 0;
+#pragma omp parallel for schedule(dynamic, 1) num_threads(n_threads > 0 ? n_threads : 1)
+    for (int b = 0; b < n_clips; ++b) {
+        double *spec = (double *)malloc(sizeof(double) * (size_t)n_filters * (size_t)ncols);
+        double *norm = (double *)malloc(sizeof(double) * (size_t)n_filters * (size_t)time_bins);
+        if (!spec || !norm ||
+            orc_gammatone_spec(audio + (size_t)b * n_samples, n_samples, coefs, n_filters, nwin, hop, ncols, spec)) {
+#pragma omp atomic write
+            bad = 1;
+        } else {
+            orc_gammatone_db(spec, n_filters * ncols);
+            (void)orc_normalise_resize_f64(spec, n_filters, ncols, time_bins, norm);   /* flat input: zeros */
+            orc_encode_hysteresis_f64(norm, n_filters, time_bins, thr_on, thr_off, n_thr,
+                                      rasters + (size_t)b * n_filters * time_bins * n_thr);
+        }
+        free(spec);
+        free(norm);
+    }
+    return bad ? -1 : 0;
+}
+
 /* ---------------------------------------------------------------------------------------------
  * LIF reservoir, SPEC.md §3 (gather form, literal) + §4 features.  float32 throughout, one
  * accumulator per neuron: presynaptic j ascending, then w_in * (active input count).

@@ -92,7 +92,7 @@ int main(void)
     long spikes = 0;
     const int layouts[3] = {0, 1, 2};
     for (int li = 0; li < 3; ++li) {
-        CHECK(lsm_reservoir_run(h, d_r, B, T, keys, 8, d_f, NULL, NULL, layouts[li], st));
+        CHECK(lsm_reservoir_run(h, d_r, B, T, keys, 8, d_f, NULL, NULL, NULL, layouts[li], st));
         HIP(hipStreamSynchronize(st));
         HIP(hipMemcpy(got, d_f, sizeof(got), hipMemcpyDeviceToHost));
         for (int b = 0; b < B; ++b) {
@@ -104,8 +104,8 @@ int main(void)
     }
     /* error path: bad key id must be refused with a message, then the handle must still work */
     int32_t bad = 11;
-    if (lsm_reservoir_run(h, d_r, B, T, &bad, 1, d_f, NULL, NULL, 0, st) == 0 || !lsm_last_error()[0]) { printf("FAIL bad key accepted\n"); return 1; }
-    CHECK(lsm_reservoir_run(h, d_r, B, T, keys, 8, d_f, NULL, NULL, 0, st));
+    if (lsm_reservoir_run(h, d_r, B, T, &bad, 1, d_f, NULL, NULL, NULL, 0, st) == 0 || !lsm_last_error()[0]) { printf("FAIL bad key accepted\n"); return 1; }
+    CHECK(lsm_reservoir_run(h, d_r, B, T, keys, 8, d_f, NULL, NULL, NULL, 0, st));
     HIP(hipStreamSynchronize(st));
     CHECK(lsm_reservoir_destroy(h));
     if (spikes == 0) { printf("FAIL reservoir never fired\n"); return 1; }

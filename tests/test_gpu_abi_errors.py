@@ -47,9 +47,9 @@ def test_bad_arguments_raise_and_library_survives():
     feats = torch.empty((2, 40), dtype=torch.float32, device="cuda")
     r = torch.from_numpy(rasters).cuda()
     rc = lib.lsm_reservoir_run(net._handle, p(r), 2, 40, C.c_void_p(key_ids.ctypes.data), 1, p(feats),
-                               None, None, 0, stream)
+                               None, None, None, 0, stream)
     assert rc < 0 and b"key id" in lib.lsm_last_error()
-    rc = lib.lsm_reservoir_run(None, p(r), 2, 40, C.c_void_p(key_ids.ctypes.data), 1, p(feats), None, None, 0, stream)
+    rc = lib.lsm_reservoir_run(None, p(r), 2, 40, C.c_void_p(key_ids.ctypes.data), 1, p(feats), None, None, None, 0, stream)
     assert rc < 0
     # invalid wiring is rejected at create time
     bad = R.build_reservoir(prm, 8)

@@ -20,11 +20,11 @@ ALL_KEYS = ['spike_counts', 'spike_variances', 'mean_spike_times', 'first_spike_
             'last_spike_times', 'mean_isi', 'isi_variances', 'burst_counts']
 
 
-def _cases(n_cases, seed):
+def _cases(n_cases, seed, n_lo=40, n_hi=700, k_hi=60):
     rng = np.random.RandomState(seed)
     for i in range(n_cases):
-        n = int(rng.randint(40, 700))
-        k = int(2 * rng.randint(2, max(3, min(n // 4, 60))))
+        n = int(rng.randint(n_lo, n_hi))
+        k = int(2 * rng.randint(2, max(3, min(n // 4, k_hi))))
         c = int(rng.randint(1, 200))
         t = int(rng.choice([1, 7, 37, 100, 255, 400]))
         yield dict(
@@ -37,12 +37,16 @@ def _cases(n_cases, seed):
             wpc=int(rng.choice([1, 2, 4, 8, 16])), seed=1000 * seed + i)
 
 
-@pytest.mark.parametrize("seed", [1, 2, 3])
-def test_random_configurations_match_the_oracle(torch_cuda, oracle_c, seed):
+@pytest.mark.parametrize("seed,n_cases,n_lo,n_hi,k_hi", [(1, 16, 40, 700, 60), (2, 16, 40, 700, 60),
+                                                       (3, 16, 40, 700, 60),
+                                                       # sizes at which the ring-row kernel exists (>= 3 quads)
+                                                       (4, 8, 700, 2700, 160), (5, 8, 700, 2700, 160)])
+def test_random_configurations_match_the_oracle(torch_cuda, oracle_c, seed, n_cases, n_lo, n_hi, k_hi):
     from lsm_speech_classifier_amd import _lib, reservoir as R, snn, synth
     from oracle import ref_numpy as O
     spikes = 0
-    for case in _cases(16, seed):
+    ring_runs = 0
+    for case in _cases(n_cases, seed, n_lo, n_hi, k_hi):
         rasters = synth.bernoulli_raster(3, case["c"], case["t"], case["density"], seed=case["seed"])
         rasters[1] = (rasters[1] * 201).astype(np.uint8)                # any non-zero byte is a spike
         wc = O.w_critico(case["k"], 2.0, case["refr"], rasters)
@@ -53,10 +57,10 @@ def test_random_configurations_match_the_oracle(torch_cuda, oracle_c, seed):
         net = snn.SNN(None, reservoir=res)
         kernels = ["dense", "sparse"]
         try:
-            net.set_kernel("band")
-            kernels.append("band")
+            net.set_kernel("ring")
+            kernels.append("ring")
         except _lib.LsmHipError:
-            pass                                       # not ring-like enough for a band table
+            pass                                       # not ring-like enough, or too small, for ring rows
         for kernel in kernels:
             net.set_kernel(kernel)
             for wpc in (0, case["wpc"]):
@@ -64,8 +68,9 @@ def test_random_configurations_match_the_oracle(torch_cuda, oracle_c, seed):
                     f, sm, vt = net.run_batch(rasters, case["keys"], want_spike_matrix=True,
                                               want_v_trace=True, waves_per_clip=wpc)
                 except _lib.LsmHipError as e:          # a forced layout this reservoir does not have
-                    assert "layout" in str(e) and (wpc != 0 or kernel == "band"), (case, str(e))
+                    assert "layout" in str(e) and wpc != 0, (case, str(e))
                     continue
+                ring_runs += kernel == "ring"
                 f, sm, vt = f.cpu().numpy(), sm.cpu().numpy(), vt.cpu().numpy()
                 for b in range(len(rasters)):
                     f_ref, sm_ref, vt_ref = oracle_c.lif_run(res, rasters[b], case["keys"], want_trace=True)
@@ -75,6 +80,7 @@ def test_random_configurations_match_the_oracle(torch_cuda, oracle_c, seed):
                     np.testing.assert_array_equal(f[b], f_ref, err_msg=msg)
                     spikes += int(sm_ref.sum())
     assert spikes > 10000                                  # the cases do exercise spiking networks
+    assert n_lo < 700 or ring_runs >= n_cases              # the large cases do run the ring-row kernel
 
 
 @pytest.mark.parametrize("n_samples,nw", [(12000, 4), (16000, 3), (24000, 2), (48000, 1), (13000, 4)])

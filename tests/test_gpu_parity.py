@@ -170,12 +170,13 @@ def _reservoir(n, k, n_out, c, rasters, **kw):
 
 
 def _kernels(net):
-    """The reservoir kernels this reservoir offers: dense rows, sparse CSC, and band rows when it is ring-like."""
+    """The reservoir kernels this reservoir offers: dense rows, sparse CSC, and ring rows when it is ring-like
+    and has at least a few quads of 256 neurons."""
     from lsm_speech_classifier_amd import _lib
     out = ["dense", "sparse"]
     try:
-        net.set_kernel("band")
-        out.insert(1, "band")
+        net.set_kernel("ring")
+        out.insert(1, "ring")
     except _lib.LsmHipError:
         pass
     net.set_kernel("auto")
@@ -188,7 +189,7 @@ def _check_against_oracle(net, rasters, oracle_c, wpc, keys=None):
         feats, sm, vt = net.run_batch(rasters, keys, want_spike_matrix=True, want_v_trace=True,
                                       waves_per_clip=wpc)
     except _lib.LsmHipError as e:
-        if "band format has no list layout" in str(e):       # a rewired list longer than one wave
+        if "no ring-row layout" in str(e):                   # the ring kernel has 1-3 layouts per reservoir
             return 1
         raise
     feats, sm, vt = feats.cpu().numpy(), sm.cpu().numpy(), vt.cpu().numpy()
@@ -211,6 +212,10 @@ def _check_against_oracle(net, rasters, oracle_c, wpc, keys=None):
     (256, 40, 100, 100, (1, 2, 4)),
     (192, 30, 64, 33, (1, 2)),
     (300, 60, 120, 200, (2, 4, 8)),
+    # ring rows: 6 whole quads / a partly filled last quad with C > 128 / 9 quads, 4 neurons of the 10th
+    (1536, 150, 600, 64, (2, 4, 8)),
+    (2000, 400, 800, 200, (2, 4, 8)),
+    (2308, 300, 700, 48, (4, 8, 16)),
 ])
 def test_reservoir_matches_oracle_all_layouts(torch_cuda, oracle_c, n, k, n_out, c, wpcs):
     from lsm_speech_classifier_amd import snn, synth
@@ -219,7 +224,7 @@ def test_reservoir_matches_oracle_all_layouts(torch_cuda, oracle_c, n, k, n_out,
     res = _reservoir(n, k, n_out, c, rasters)
     net = snn.SNN(None, reservoir=res)
     kernels = _kernels(net)
-    assert "band" in kernels                             # small-world reservoirs are ring-like
+    assert ("ring" in kernels) == (n >= 1000)            # small-world reservoirs are ring-like; ring rows need a few quads
     for kernel in kernels:                               # every kernel, every layout
         net.set_kernel(kernel)
         for wpc in wpcs:
@@ -304,9 +309,11 @@ def test_full_size_properties(torch_cuda, oracle_c):
     perm = np.random.RandomState(0).permutation(B)                       # batch order independence
     f2, _, _ = net.run_batch(dev[torch.from_numpy(perm).cuda()], waves_per_clip=0)
     np.testing.assert_array_equal(f2.cpu().numpy(), f[perm])
-    for kernel in _kernels(net):                                         # kernels and layouts agree
+    kernels = _kernels(net)
+    assert "ring" in kernels
+    for kernel in kernels:                                               # kernels and layouts agree
         net.set_kernel(kernel)
-        for wpc in (1, 4, 16):
+        for wpc in ((2, 4) if kernel == "ring" else (1, 4, 16)):         # (ring rows at N=1000: 2 or 4 waves)
             fw, _, _ = net.run_batch(dev, waves_per_clip=wpc)
             np.testing.assert_array_equal(fw.cpu().numpy(), f)
     net.set_kernel("auto")
@@ -325,8 +332,8 @@ def test_large_reservoirs_match_oracle(torch_cuda, oracle_c, n, k, n_out, c, cli
     keys = ["spike_counts", "spike_variances", "mean_spike_times", "mean_isi", "isi_variances"]
     ref = oracle_c.lif_run_batch(res, rasters, keys, n_threads=clips)
     assert ref[:, :n_out].sum() > 0
-    assert "band" in _kernels(net)
-    for kernel in ("dense", "band", "sparse"):           # 64 / 262 MB dense tables, band rows, CSC scatter
+    assert "ring" in _kernels(net)
+    for kernel in ("dense", "ring", "sparse"):           # 64 / 262 MB dense tables, ring rows, CSC scatter
         net.set_kernel(kernel)
         for wpc in (0, 8):
             feats, _, _ = net.run_batch(rasters, keys, waves_per_clip=wpc)
