@@ -266,6 +266,7 @@ def run_rank(args):
             dist.barrier()
             torch.cuda.synchronize()
 
+    hp.prime(audio_pinned if args.from_host else audio)   # set-up: every stream's allocator pool and first launch
     hp.fork_from_current()             # inputs were produced on the default stream
     for _ in range(args.warmup):
         out = step()

@@ -106,6 +106,22 @@ def _synthetic_audio(commands, per_class: int):
     return list(synth.class_chirps(labels, seed=1234)), list(labels)
 
 
+def collect_audio(commands=None, dataset_root=None, max_per_class: int = MAX_SAMPLES_PER_CLASS,
+                  synthetic_per_class: int = 0):
+    """The clips create_dataset() would encode, as arrays: (n, 16000) float32 and int32 labels (label =
+    position in the class list) -- the entry of the in-memory route (extract_lsm_features.main_from_audio),
+    which skips File 1.  Empty arrays when nothing could be read."""
+    commands = list(COMMANDS if commands is None else commands)
+    root = Path(DATASET_ROOT if dataset_root is None else dataset_root)
+    if synthetic_per_class > 0:
+        clips, labels = _synthetic_audio(commands, synthetic_per_class)
+    else:
+        clips, labels = _collect_audio(commands, root, max_per_class)
+    if not clips:
+        return np.zeros((0, int(SAMPLE_RATE * DURATION)), dtype=np.float32), np.zeros(0, dtype=np.int32)
+    return np.stack(clips).astype(np.float32, copy=False), np.asarray(labels, dtype=np.int32)
+
+
 def create_dataset(n_filters: int, filterbank: str, commands=None, dataset_root=None,
                    max_per_class: int = MAX_SAMPLES_PER_CLASS, synthetic_per_class: int = 0,
                    output_file: str = OUTPUT_FILE, packed: bool = False):

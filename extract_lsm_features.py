@@ -73,7 +73,8 @@ def extract_all_features(lsm, spike_data, feature_keys, desc=""):
     if hasattr(lsm, "run_batch"):
         import torch
         from lsm_speech_classifier_amd import dist as lsm_dist
-        rank, _, world = lsm_dist.env_world()
+        from lsm_speech_classifier_amd.snn import FEATURE_KEYS
+        rank, world = lsm_dist.group_world()         # the initialised process group, else a single process
         n = len(spike_data)
         lo, hi = lsm_dist.shard_range(n, rank, world) if world > 1 else (0, n)
         if desc and rank == 0:
@@ -83,7 +84,7 @@ def extract_all_features(lsm, spike_data, feature_keys, desc=""):
             feats, _, _ = lsm.run_batch(np.ascontiguousarray(spike_data[a:min(hi, a + RUN_BATCH)]),
                                         feature_keys)
             rows.append(feats)
-        n_feat = len([k for k in feature_keys]) * lsm.num_output_neurons
+        n_feat = len([k for k in feature_keys if k in FEATURE_KEYS]) * lsm.num_output_neurons   # as run_batch filters
         local = torch.cat(rows) if rows else torch.empty((0, n_feat), dtype=torch.float32,
                                                          device=lsm.device)
         return lsm_dist.gather_rows(local, n).cpu().numpy()
@@ -134,6 +135,54 @@ def run_network_diagnostics(lsm, X_sample_batch):
     return avg
 
 
+def main_from_audio(audio, labels, n_filters: int, filterbank: str, feature_set: str, multiplier: float,
+                    leak_variance_divisor: float = None, batch: int = 1024):
+    """Stages 1 + 2 without File 1: audio (n, 16000) float32 + labels -> File 2, the same arrays main() writes
+    after create_dataset() (tests/test_gpu_hotpath.py compares them).  The split, w_critico (first <= 500
+    training clips), the reservoir and the diagnostics follow main() line by line; the features come from
+    `pipeline.HotPath`: every batch of clips goes filterbank -> encoder -> reservoir on the GPU, consecutive
+    batches overlapped on rotating streams, and no raster ever reaches the host.  Single process."""
+    from sklearn.model_selection import train_test_split
+    from sklearn.preprocessing import StandardScaler
+    from lsm_speech_classifier_amd import frontend, pipeline
+    from lsm_speech_classifier_amd.snn import SNN, SimulationParams
+
+    audio = np.ascontiguousarray(audio, dtype=np.float32)
+    labels = np.asarray(labels, dtype=np.int32)
+    if len(audio) == 0:
+        print("Error: no audio clips")
+        return
+    idx_train, idx_test, y_train, y_test = train_test_split(
+        np.arange(len(audio)), labels, test_size=0.2, random_state=42, stratify=labels)
+    fe = frontend.SpikeFrontEnd(n_filters, filterbank)
+    head = fe.encode(audio[idx_train[:500]]).cpu().numpy()          # what w_critico and the diagnostics look at
+    params = SimulationParams(
+        num_neurons=NUM_NEURONS, mean_weight=0.0, num_output_neurons=NUM_OUTPUT_NEURONS,
+        membrane_threshold=MEMBRANE_THRESHOLD, leak_coefficient=LEAK_COEFFICIENT,
+        refractory_period=REFRACTORY_PERIOD, small_world_graph_p=SMALL_WORLD_P,
+        small_world_graph_k=SMALL_WORLD_K, input_spike_times=head[0],
+        leak_variance_divisor=leak_variance_divisor)
+    optimal_weight = calculate_theoretical_w_critico(params, head) * multiplier
+    print(f"Using weight: {optimal_weight:.8f} (multiplier: {multiplier:.2f})")
+    if leak_variance_divisor:
+        print(f"Using Heterogeneous Leak. Divisor: {leak_variance_divisor}")
+    params.mean_weight = optimal_weight
+    params.weight_variance = WEIGHT_VARIANCE
+    lsm = SNN(simulation_params=params)
+    run_network_diagnostics(lsm, head)
+    keys = FEATURE_SETS[feature_set]
+    print(f"Extracting feature set: '{feature_set}' ({len(idx_train)} + {len(idx_test)} clips, audio -> features on the GPU)")
+    X_train_feat = pipeline.features_from_audio(audio[idx_train], fe, lsm, keys, batch=batch)
+    X_test_feat = pipeline.features_from_audio(audio[idx_test], fe, lsm, keys, batch=batch)
+    scaler = StandardScaler()
+    X_train_scaled = scaler.fit_transform(X_train_feat)
+    X_test_scaled = scaler.transform(X_test_feat)
+    np.savez_compressed(FEATURE_FILE, X_train_features=X_train_scaled, y_train=y_train,
+                        X_test_features=X_test_scaled, y_test=y_test, feature_set=feature_set,
+                        leak_variance_divisor=leak_variance_divisor)
+    print(f"Extraction complete. Features saved to '{FEATURE_FILE}'")
+
+
 def main(feature_set: str, multiplier: float, leak_variance_divisor: float = None):
     from sklearn.model_selection import train_test_split
     from sklearn.preprocessing import StandardScaler
@@ -168,6 +217,7 @@ def main(feature_set: str, multiplier: float, leak_variance_divisor: float = Non
     print(f"Extracting feature set: '{feature_set}'")
     X_train_feat = extract_all_features(lsm, X_train, keys, "Training")
     X_test_feat = extract_all_features(lsm, X_test, keys, "Testing")
+    lsm_dist.finish()
     if rank != 0:
         return
 

@@ -120,7 +120,8 @@ int lsm_reservoir_destroy(lsm_reservoir *h);
 /* Kernel used by lsm_reservoir_run for this handle: 0 = choose (register accumulation over dense
  * presynaptic rows; over ring rows -- dense ring window + list of the synapses outside it -- for ring-like
  * reservoirs whose dense table exceeds the L2 caches), 1 = sparse CSC scatter through LDS, 2 = dense rows,
- * 3 = ring rows (refused when the reservoir is not ring-like or has fewer than ~700 neurons).  All produce
+ * 3 = ring rows (refused when the reservoir is not ring-like or has fewer than ~700 neurons), 4 = ring rows
+ * restricted to the layouts with contiguous quad ownership (tests; 3 prefers the strided ones).  All produce
  * bit-identical results (SPEC.md §3).  num_neurons <= 8192. */
 int lsm_reservoir_set_kernel(lsm_reservoir *h, int mode);
 

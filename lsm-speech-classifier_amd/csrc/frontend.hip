@@ -337,9 +337,7 @@ int launch_spec_to_spikes(const T *db, int n_clips, int n_filters, int ncols, in
     const size_t lds = 64 + (size_t)n_filters * (((size_t)time_bins * n_thr + 31) / 32) * 4;
     LSM_REQUIRE(lds <= 160 * 1024, "raster stage of %zu bytes exceeds one CU's LDS", lds);
     auto fn = spec_to_spikes_kernel<T>;
-    if (lds > 64 * 1024)
-        LSM_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(fn),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    if (lds > 64 * 1024) lsm_allow_big_lds(reinterpret_cast<const void *>(fn));
     hipLaunchKernelGGL(fn, dim3(n_clips), dim3(256), lds, (hipStream_t)stream, a);
     LSM_CHECK_HIP(hipGetLastError());
     return LSM_OK;
@@ -448,7 +446,8 @@ LSM_API int lsm_gammatone_spec_f64(const float *audio, int n_clips, int n_sample
     LSM_REQUIRE((long)(ncols - 1) * hop + nwin <= n_samples, "columns exceed the clip");
     LSM_REQUIRE(n_samples >= 8, "clips shorter than 8 samples are not supported");
     const long n_waves = (long)((n_filters + 63) / 64) * n_clips;
-    static const int wpb_env = [] {                      // experiments only (exp/wpb_sweep.sh)
+#if LSM_EXPERIMENT_HOOKS                                // diagnostic builds only (exp/wpb_sweep.sh, exp/resv_sweep.sh)
+    static const int wpb_env = [] {
         const char *e = getenv("LSM_GT_WPB");
         const int v = e ? atoi(e) : 0;
         return v >= 1 && v <= GT_MAX_WPB ? v : 0;
@@ -459,6 +458,9 @@ LSM_API int lsm_gammatone_spec_f64(const float *audio, int n_clips, int n_sample
         const int v = e ? atoi(e) : -1;
         return v >= 0 && v <= 160 * 1024 ? v : -1;
     }();
+#else
+    constexpr int wpb = 4, lds_env = -1;
+#endif
     // CU-exclusive placement for small launches.  The kernel uses no LDS; the reservation (half of
     // a CU's LDS plus 1 KB) only caps the dispatcher at ONE gammatone workgroup per CU, so launches
     // that overlap on other streams spread over the free CUs instead of stacking their waves on the
@@ -480,14 +482,9 @@ LSM_API int lsm_gammatone_spec_f64(const float *audio, int n_clips, int n_sample
     const int nw = (nwin + hop - 1) / hop;
 #define LSM_GT(NW)                                                                            \
     {                                                                                         \
-        if (lds > 0) {                                                                        \
-            LSM_CHECK_HIP(hipFuncSetAttribute(                                                \
-                reinterpret_cast<const void *>(&gammatone_kernel<NW, true, true>),            \
-                hipFuncAttributeMaxDynamicSharedMemorySize, lds));                            \
-            LSM_CHECK_HIP(hipFuncSetAttribute(                                                \
-                reinterpret_cast<const void *>(&gammatone_kernel<NW, false, false>),          \
-                hipFuncAttributeMaxDynamicSharedMemorySize, lds));                            \
-        }                                                                                     \
+        if (lds > 64 * 1024)                                                                  \
+            lsm_allow_big_lds(fast ? reinterpret_cast<const void *>(&gammatone_kernel<NW, true, true>)   \
+                                   : reinterpret_cast<const void *>(&gammatone_kernel<NW, false, false>)); \
         if (fast)                                                                             \
             hipLaunchKernelGGL((gammatone_kernel<NW, true, true>), grid, block, lds,          \
                                (hipStream_t)stream, audio, n_clips, n_samples, coefs,         \

@@ -6,10 +6,10 @@
 // N >= 4000 that is what bounds it (profiles/r01_big_traffic.json: 8-17x the algorithmic bytes).  A
 // Watts-Strogatz reservoir is a ring lattice with ~10 % rewired edges, so row j is stored as
 //   * its ring WINDOW: the weights onto the targets from the 256-aligned start of j-H .. j+H (circular),
-//     dense, in natural target order, 16-byte granules -- fetched with bounds-checked 16-byte buffer loads:
-//     a lane owns FOUR consecutive neurons of a 256-neuron "quad", a wave QL quads, and a quad the window
-//     does not reach is an out-of-range load that returns zeros without touching memory, so every wave runs
-//     the same straight-line code for every row (no per-slot index arithmetic, no branches);
+//     dense, in natural target order -- fetched with bounds-checked 16-byte buffer loads: a lane owns FOUR
+//     consecutive neurons of a 256-neuron "quad", and a quad the window does not reach is an out-of-range
+//     load that returns zeros without touching memory, so every wave runs the same straight-line code for
+//     every row (no per-slot index arithmetic, no branches around loads: the counted waits stay exact);
 //   * a LIST of the synapses outside the window ("rewired"), per (row, wave), unpadded: {LDS byte offset of
 //     the target's scratch word, weight bits}.  One lane per entry PARKS the weight in the wave's scratch
 //     array, every lane reads back its own SL words (16-byte LDS reads), the parked words are cleared
@@ -19,14 +19,26 @@
 // (x + 0 = x in float32 for every x the sum can take), and rows are applied in ascending j: every target's
 // float32 sum keeps the oracle's order and is bit-identical.
 //
-// Rows are pipelined: P rows' loads are in flight while the oldest is applied, so the Infinity-Cache / HBM
-// latency of the row gathers overlaps the LDS hand-off and the register adds of the rows before it.
+// Quad ownership.  CONTIGUOUS: wave w owns quads w*QL .. w*QL+QL-1; a window (<= 8 quads) then lies in two or
+// three waves, which issue QL window loads per row while the others issue out-of-range ones.  STRIDED: wave w
+// owns quads w, w+WPC, w+2*WPC, ...; a window of <= WPC quads puts exactly ONE quad into every wave, so every
+// wave issues one useful 1 KB load per row (a quarter of the load instructions, all eight waves keep row
+// gathers in flight, and 8 rows fit the registers that 4 took before).  STRIDED needs NQ % WPC == 0 (the
+// residues must survive the ring's wrap) and window quads <= WPC; the host offers it when that holds.
+//
+// Spike exchange: per QUAD lists (ascending inside a quad: lane, then the lane's four neurons) + one count
+// per quad; quad order = ascending neuron order under both ownerships, so lane l of a consumer finds the
+// l-th spiking neuron of the clip by a prefix over the quad counts.
+//
+// Rows are pipelined: P rows' loads are in flight while the oldest is applied, and the LDS hand-off of row
+// m+1 is issued before the adds of row m.
 #pragma once
 #include "lif_kernel.h"
 
 namespace lsm_lif {
 
-// a += b on four floats.  LSM_RING_SCALAR_ADD: four v_add_f32 instead of two v_pk_add_f32 (experiment switch)
+// a += b on four floats.  LSM_RING_SCALAR_ADD: four v_add_f32 instead of two v_pk_add_f32 (experiment switch;
+// measured equal: the kernel is bound by the row gathers, not by vector issue)
 #if defined(LSM_RING_SCALAR_ADD)
 #define LSM_RING_ADD4(a, b)                                                          \
     {                                                                                \
@@ -43,7 +55,7 @@ namespace lsm_lif {
 
 #ifndef LSM_RING_ABLATE
 #define LSM_RING_ABLATE 0   // diagnostic builds only (1, 2, 8 give WRONG results): 1 = no window loads, 2 = no LDS
-#endif                      // hand-off, 4 = window adds only for rows that reach my quads (exact), 8 = no list loads
+#endif                      // hand-off, 8 = no list loads
 
 struct RingArgs {
     int N, C, T, B;
@@ -72,36 +84,42 @@ typedef uint32_t ring_u4 __attribute__((ext_vector_type(4)));
 typedef uint32_t ring_u2 __attribute__((ext_vector_type(2)));
 
 constexpr int RING_DUMP_WORDS = 64;                 // LDS words 0..63: where idle lanes park
+constexpr int RING_MAX_QUADS = 32;                  // 8192 neurons
 __host__ __device__ constexpr int ring_stride(int sl) { return sl == 4 ? 4 : sl + 4; }   // scratch words per lane:
                                                     // 16-byte reads of 16 lanes then fall on 16 distinct 4-bank groups
 
-// scratch WORD index (from the start of LDS) of neuron i in the layout (QL quads per wave)
-__host__ __device__ inline int ring_scr_word(int i, int ql)
+// owner of quad g in a layout: (wave, register quad)
+__host__ __device__ inline int ring_wave_of_quad(int g, int ql, int wpc, bool strided) { return strided ? g % wpc : g / ql; }
+__host__ __device__ inline int ring_slot_of_quad(int g, int ql, int wpc, bool strided) { return strided ? g / wpc : g % ql; }
+
+// scratch WORD index (from the start of LDS) of neuron i
+__host__ __device__ inline int ring_scr_word(int i, int ql, int wpc, bool strided)
 {
-    const int sl = 4 * ql, npw = sl * 64;
-    const int w = i / npw, rem = i - w * npw;
-    const int q = rem >> 8, lane = (rem & 255) >> 2, h = rem & 3;
-    return RING_DUMP_WORDS + (w * 64 + lane) * ring_stride(sl) + q * 4 + h;
+    const int g = i >> 8, lane = (i & 255) >> 2, h = i & 3;
+    return RING_DUMP_WORDS + (ring_wave_of_quad(g, ql, wpc, strided) * 64 + lane) * ring_stride(4 * ql) +
+           ring_slot_of_quad(g, ql, wpc, strided) * 4 + h;
 }
 
 // QL: quads (256 neurons, 4 per lane) per wave; WPC: waves per clip; INREG: the wave's input-map entries sit
-// in registers (else they stream from global memory every step).
-template <int QL, int WPC, bool INREG>
+// in registers (else they stream from global memory every step); STRIDED: quad ownership (see above).
+template <int QL, int WPC, bool INREG, bool STRIDED>
 __global__ __launch_bounds__(WPC * 64) void lif_ring_kernel(const RingArgs a)
 {
     constexpr int SL = 4 * QL;
-    constexpr int NPW = SL * 64;
-    constexpr int NPAD = NPW * WPC;
+    constexpr int NQP = QL * WPC;                   // quads of the padded layout (<= 32)
+    constexpr int NPAD = NQP * 256;
     constexpr int NT = WPC * 64;
     constexpr int STRIDE = ring_stride(SL);
-    constexpr int P = QL >= 4 ? 4 : 8;              // rows in flight (QL*4 + 2 registers each)
+    constexpr int WL = STRIDED ? 1 : QL;            // window loads per row and wave
+    constexpr int P = STRIDED ? 8 : (QL >= 4 ? 4 : 8);   // rows in flight (WL*4 + 2 registers each)
     constexpr uint32_t RSRC_FLAGS = 0x00020000u;    // raw dword buffer, gfx9 family
+    static_assert(NQP <= RING_MAX_QUADS, "at most 8192 neurons");
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint32_t *scr = reinterpret_cast<uint32_t *>(smem);                               // dump + WPC*64*STRIDE
-    uint16_t *wlist = reinterpret_cast<uint16_t *>(scr + RING_DUMP_WORDS + WPC * 64 * STRIDE);   // 2*NPAD
-    uint32_t *wcnt = reinterpret_cast<uint32_t *>(wlist + 2 * NPAD);                  // 2*16 counts + 2 stats
-    uint4 *feat = reinterpret_cast<uint4 *>(wcnt + 64);                               // n_out
+    uint16_t *wlist = reinterpret_cast<uint16_t *>(scr + RING_DUMP_WORDS + WPC * 64 * STRIDE);   // 2*NPAD: 256 per quad
+    uint32_t *wcnt = reinterpret_cast<uint32_t *>(wlist + 2 * NPAD);                  // 2*32 quad counts + 2 stats
+    uint4 *feat = reinterpret_cast<uint4 *>(wcnt + 128);                              // n_out
     uint32_t *bits = reinterpret_cast<uint32_t *>(feat + a.n_out);                    // T*CW
 
     const int tid = threadIdx.x;
@@ -109,10 +127,12 @@ __global__ __launch_bounds__(WPC * 64) void lif_ring_kernel(const RingArgs a)
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int b = blockIdx.x;
     const int N = a.N, T = a.T, CW = a.CW;
+    // global quad of my register quad q
+#define LSM_RING_GQ(q) (STRIDED ? (q) * WPC + w : w * QL + (q))
 
     // ---- prologue: zero LDS state, bit-pack the clip's raster time-major ----
     for (int i = tid; i < RING_DUMP_WORDS + WPC * 64 * STRIDE; i += NT) scr[i] = 0u;
-    if (tid < 64) wcnt[tid] = 0u;
+    for (int i = tid; i < 128; i += NT) wcnt[i] = 0u;
     for (int i = tid; i < a.n_out; i += NT) feat[i] = make_uint4(0, 0, 0, 0);
     for (int i = tid; i < T * CW; i += NT) bits[i] = 0u;
     __syncthreads();
@@ -141,14 +161,14 @@ __global__ __launch_bounds__(WPC * 64) void lif_ring_kernel(const RingArgs a)
         }
     }
 
-    // my neurons: register r = 4*q + h  <->  neuron (w*QL + q)*256 + lane*4 + h
+    // my neurons: register r = 4*q + h  <->  neuron GQ(q)*256 + lane*4 + h
     // oref[r] = (output slot + 1) | (refractory countdown << 16): one register for both, "held" is one
     // unsigned compare, the slot is unpacked only when the neuron fires.
     float v[SL], lam[SL];
     uint32_t oref[SL];
 #pragma unroll
     for (int q = 0; q < QL; ++q) {
-        const int i0 = (w * QL + q) * 256 + lane * 4;
+        const int i0 = LSM_RING_GQ(q) * 256 + lane * 4;
         const float4 l4 = *reinterpret_cast<const float4 *>(a.leak + i0);
         const int4 o4 = *reinterpret_cast<const int4 *>(a.oslot + i0);
         const float l[4] = {l4.x, l4.y, l4.z, l4.w};
@@ -226,30 +246,30 @@ __global__ __launch_bounds__(WPC * 64) void lif_ring_kernel(const RingArgs a)
     for (int t = 0; t < T; ++t) {
         const int cur = t & 1, prv = cur ^ 1;
         const uint16_t *list_prev = wlist + prv * NPAD;
-        uint16_t *list_cur = wlist + cur * NPAD + w * NPW;
+        uint16_t *list_cur = wlist + cur * NPAD;
 
         ring_f4 cin[QL];
 #pragma unroll
         for (int q = 0; q < QL; ++q) cin[q] = (ring_f4){0.0f, 0.0f, 0.0f, 0.0f};
 
-        // ---- spiking neurons of step t-1: prefix of the per-wave counts, lane l <- l-th neuron ----
-        const uint32_t cv = wcnt[prv * 16 + (lane & 15)];
+        // ---- spiking neurons of step t-1: prefix of the per-quad counts, lane l <- l-th neuron ----
+        const uint32_t cv = wcnt[prv * 32 + (lane & 31)];
         uint32_t total = 0u;
 #pragma unroll
-        for (int q = 0; q < WPC; ++q) total += __builtin_amdgcn_readlane(cv, q);
+        for (int g = 0; g < NQP; ++g) total += __builtin_amdgcn_readlane(cv, g);
 
         for (uint32_t l0 = 0; l0 < total; l0 += 64) {
             const uint32_t l = l0 + lane;
-            uint32_t wsel = 0u, pbase = 0u, run = 0u;      // (the prefix is formed again per chunk: it would
-#pragma unroll                                             //  otherwise hold WPC scalar registers across the rows)
-            for (int q = 1; q < WPC; ++q) {
-                run += __builtin_amdgcn_readlane(cv, q - 1);
+            uint32_t gsel = 0u, pbase = 0u, run = 0u;      // (the prefix is formed again per chunk: it would
+#pragma unroll                                             //  otherwise hold NQP scalar registers across the rows)
+            for (int g = 1; g < NQP; ++g) {
+                run += __builtin_amdgcn_readlane(cv, g - 1);
                 const bool ge = l >= run;
-                wsel += ge ? 1u : 0u;
+                gsel += ge ? 1u : 0u;
                 pbase = ge ? run : pbase;
             }
             const bool valid = l < total;
-            const int jl = valid ? (int)list_prev[wsel * NPW + (l - pbase)] : 0;
+            const int jl = valid ? (int)list_prev[gsel * 256 + (l - pbase)] : 0;
             // ---- lane l: everything a wave needs to fetch row jl, computed for 64 rows at once ----
             // window = targets from the 256-aligned start of jl-H up to jl+H (circular in N); in the stored row
             // quad (q0 + p) mod NQ sits at position p.  Bytes of the row that exist: up to the window's end.
@@ -258,14 +278,20 @@ __global__ __launch_bounds__(WPC * 64) void lif_ring_kernel(const RingArgs a)
             const int q0 = a0 >> 8, q1 = b0 >> 8;
             int p1 = q1 - q0; p1 += p1 < 0 ? NQ : 0;
             const uint32_t p_nrec = valid ? (uint32_t)(p1 * 1024 + (((b0 & 255) >> 2) + 1) * 16) : 0u;
-            // position of my wave's first quad in that row: quads below q0 sit NQ further (wrapped window); a
-            // wave never holds both ends of a window (host: window quads + QL <= NQ)
-            const int g0 = w * QL;
-            const int base = (g0 + QL - 1 < q0) ? g0 - q0 + NQ : g0 - q0;
-            const uint32_t p_soff = (uint32_t)(base * 1024);            // negative: wraps to > any num_records
-            // rows whose window reaches none of my quads (two thirds of them at 8 waves per clip): their
-            // window loads run with one active lane and their window adds are skipped
-            const unsigned long long inmask = __ballot(valid && base + QL > 0 && base <= p1);
+            uint32_t p_soff;
+            if (STRIDED) {
+                // the one window quad with residue w (NQ % WPC == 0): position (w - q0) mod WPC, global quad
+                // (q0 + position) mod NQ, my register quad = that / WPC -- carried in the offset's low bits
+                int ph = (w - q0) % WPC; ph += ph < 0 ? WPC : 0;
+                int gh = q0 + ph; gh -= gh >= NQ ? NQ : 0;
+                p_soff = (uint32_t)(ph * 1024) | (uint32_t)(gh / WPC);
+            } else {
+                // position of my wave's first quad in that row: quads below q0 sit NQ further (wrapped window); a
+                // wave never holds both ends of a window (host: window quads + QL <= NQ)
+                const int g0 = w * QL;
+                const int base = (g0 + QL - 1 < q0) ? g0 - q0 + NQ : g0 - q0;
+                p_soff = (uint32_t)(base * 1024);                       // negative: wraps to > any num_records
+            }
             const uint64_t baddr = band_base + (uint64_t)(uint32_t)jl * a.pitch;
             const uint32_t p_blo = (uint32_t)baddr, p_bhi = (uint32_t)(baddr >> 32);
             uint32_t r0 = 0u, r1 = 0u;
@@ -278,10 +304,10 @@ __global__ __launch_bounds__(WPC * 64) void lif_ring_kernel(const RingArgs a)
             const uint32_t p_rnrec = (r1 - r0) * 8u;
             const int n = (int)min(64u, total - l0);
 
-            ring_f4 wv[P][QL];
+            ring_f4 wv[P][WL];
             ring_u2 re[P];
             ring_f4 got[2][QL];
-            bool iw[P];                          // buffer p holds a row whose window reaches my quads
+            uint32_t qh[P];                      // STRIDED: register quad the window load of buffer p belongs to
             // LOAD(p, m): issue the loads of the chunk's row m (a scalar) into buffer p.  Rows >= n do not
             // exist: their num_records is 0, every load is out of range and returns zeros without traffic.
 #define LSM_RING_LOAD(p, m)                                                                     \
@@ -297,12 +323,12 @@ __global__ __launch_bounds__(WPC * 64) void lif_ring_kernel(const RingArgs a)
         const uint32_t rnrec = __builtin_amdgcn_readlane(p_rnrec, mm) & live;                   \
         const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc(                    \
             reinterpret_cast<void *>(((uint64_t)bhi << 32) | blo), 0, (int)nrec, RSRC_FLAGS);   \
-        iw[p] = ((inmask >> mm) & 1ull) != 0ull && (m) < n;                                     \
-        _Pragma("unroll") for (int q = 0; q < QL; ++q) {                                        \
+        qh[p] = soff & 1023u;                                                                   \
+        _Pragma("unroll") for (int q = 0; q < WL; ++q) {                                        \
             /* the whole byte offset goes through the VGPR (opaque scalar: nothing is folded into the    */ \
             /* instruction's immediate), so a quad in front of the window is a huge unsigned offset and  */ \
             /* out of range whatever the address adder does with a carry                                  */ \
-            uint32_t so = soff + (uint32_t)q * 1024u;                                           \
+            uint32_t so = (STRIDED ? (soff & ~1023u) : soff) + (uint32_t)q * 1024u;             \
             asm volatile("" : "+s"(so));                                                        \
             if (LSM_RING_ABLATE & 1) {                                                          \
                 wv[p][q] = (ring_f4){0.0f, 0.0f, 0.0f, 0.0f};                                   \
@@ -344,7 +370,11 @@ __global__ __launch_bounds__(WPC * 64) void lif_ring_kernel(const RingArgs a)
 #define LSM_RING_ADD(p, g)                                                                      \
     {                                                                                           \
         _Pragma("unroll") for (int q = 0; q < QL; ++q) LSM_RING_ADD4(cin[q], got[g][q])         \
-        if (!(LSM_RING_ABLATE & 4) || iw[p]) {                                                  \
+        if (STRIDED) {                                                                          \
+            /* the window quad lands in register quad qh[p] (wave-uniform): one arm of QL */     \
+            _Pragma("unroll") for (int q = 0; q < QL; ++q)                                      \
+                if (QL == 1 || qh[p] == (uint32_t)q) LSM_RING_ADD4(cin[q], wv[p][0])            \
+        } else {                                                                                \
             _Pragma("unroll") for (int q = 0; q < QL; ++q) LSM_RING_ADD4(cin[q], wv[p][q])      \
         }                                                                                       \
         __builtin_amdgcn_sched_barrier(0);                                                      \
@@ -370,10 +400,11 @@ __global__ __launch_bounds__(WPC * 64) void lif_ring_kernel(const RingArgs a)
         wave_lds_fence();
 
         // ---- neuron update, quad by quad: leak/integrate/threshold by select, then (only if a neuron of the
-        //      quad fired) its entries of the step's spike list and the feature accumulators ----
+        //      quad fired) its entries of the quad's spike list and the feature accumulators ----
         int nspk = 0;
 #pragma unroll
         for (int q = 0; q < QL; ++q) {
+            const int gq = LSM_RING_GQ(q);
             const ring_u4 nin = *reinterpret_cast<const ring_u4 *>(myscr + 4 * q);
             *reinterpret_cast<ring_u4 *>(myscr + 4 * q) = (ring_u4){0u, 0u, 0u, 0u};
             const uint32_t nn[4] = {nin.x, nin.y, nin.z, nin.w};
@@ -392,14 +423,15 @@ __global__ __launch_bounds__(WPC * 64) void lif_ring_kernel(const RingArgs a)
                 oref[r] += held ? 0xFFFF0000u : (fire ? ref_set : 0u);
                 bq[h] = __ballot(fire);
             }
+            int nq = 0;
             if ((bq[0] | bq[1] | bq[2] | bq[3]) != 0ull) {
                 // ascending neuron order inside a quad: lane, then h
-                int rank = nspk + lane_rank(bq[0]) + lane_rank(bq[1]) + lane_rank(bq[2]) + lane_rank(bq[3]);
+                int rank = lane_rank(bq[0]) + lane_rank(bq[1]) + lane_rank(bq[2]) + lane_rank(bq[3]);
 #pragma unroll
                 for (int h = 0; h < 4; ++h) {
                     const int r = 4 * q + h;
                     if ((bq[h] >> lane) & 1ull) {
-                        list_cur[rank] = (uint16_t)((w * QL + q) * 256 + lane * 4 + h);
+                        list_cur[gq * 256 + rank] = (uint16_t)(gq * 256 + lane * 4 + h);
                         rank += 1;
                         hf |= 1u << r;
                         const int osl = (int)(oref[r] & 0xFFFFu) - 1;
@@ -420,12 +452,14 @@ __global__ __launch_bounds__(WPC * 64) void lif_ring_kernel(const RingArgs a)
                         }
                     }
                 }
-                nspk += __popcll(bq[0]) + __popcll(bq[1]) + __popcll(bq[2]) + __popcll(bq[3]);
+                nq = __popcll(bq[0]) + __popcll(bq[1]) + __popcll(bq[2]) + __popcll(bq[3]);
             }
+            if (lane == 0) wcnt[cur * 32 + gq] = (uint32_t)nq;
+            nspk += nq;
             if (trace) {
 #pragma unroll
                 for (int h = 0; h < 4; ++h) {
-                    const int i = (w * QL + q) * 256 + lane * 4 + h;
+                    const int i = gq * 256 + lane * 4 + h;
                     if (i < N) {
                         if (a.spike_matrix)
                             a.spike_matrix[((size_t)b * T + t) * N + i] = (uint8_t)((bq[h] >> lane) & 1ull);
@@ -435,18 +469,18 @@ __global__ __launch_bounds__(WPC * 64) void lif_ring_kernel(const RingArgs a)
             }
         }
         tot_spk += (uint32_t)nspk;
-        if (lane == 0) wcnt[cur * 16 + w] = (uint32_t)nspk;
         __syncthreads();
     }
+#undef LSM_RING_GQ
 
     // ---- epilogue: health statistics, then SPEC.md §4 features from the integer accumulators ----
     if (a.stats) {
-        atomicAdd(&wcnt[32], (uint32_t)__popc(hf));
-        if (lane == 0) atomicAdd(&wcnt[33], tot_spk);
+        atomicAdd(&wcnt[64], (uint32_t)__popc(hf));
+        if (lane == 0) atomicAdd(&wcnt[65], tot_spk);
         __syncthreads();
         if (tid == 0) {
-            a.stats[2 * b] = (int32_t)wcnt[32];
-            a.stats[2 * b + 1] = (int32_t)wcnt[33];
+            a.stats[2 * b] = (int32_t)wcnt[64];
+            a.stats[2 * b + 1] = (int32_t)wcnt[65];
         }
     }
     const int nf = a.n_keys * a.n_out;
@@ -478,23 +512,30 @@ __global__ __launch_bounds__(WPC * 64) void lif_ring_kernel(const RingArgs a)
 
 typedef void (*ring_fn_t)(const RingArgs);
 
-template <int QL, bool INREG>
+template <int QL, bool INREG, bool STRIDED>
 ring_fn_t pick_ring_wpc(int wpc)
 {
     switch (wpc) {
-    case 2: return lif_ring_kernel<QL, 2, INREG>;
-    case 4: return lif_ring_kernel<QL, 4, INREG>;
-    case 8: return lif_ring_kernel<QL, 8, INREG>;
+    case 2: return lif_ring_kernel<QL, 2, INREG, STRIDED>;
+    case 4: return lif_ring_kernel<QL, 4, INREG, STRIDED>;
+    case 8: return lif_ring_kernel<QL, 8, INREG, STRIDED>;
     case 16:
-        if constexpr (QL < 4) return lif_ring_kernel<QL, 16, INREG>;     // N <= 8192 = 16 waves x 2 quads
+        if constexpr (QL < 4) return lif_ring_kernel<QL, 16, INREG, STRIDED>;     // N <= 8192 = 16 waves x 2 quads
         else return nullptr;
     default: return nullptr;
     }
 }
 
+template <int QL>
+ring_fn_t pick_ring(int wpc, bool inreg, bool strided)
+{
+    if (strided) return inreg ? pick_ring_wpc<QL, true, true>(wpc) : pick_ring_wpc<QL, false, true>(wpc);
+    return inreg ? pick_ring_wpc<QL, true, false>(wpc) : pick_ring_wpc<QL, false, false>(wpc);
+}
+
 // one definition per translation unit lif_ring_<ql>.hip
-ring_fn_t pick_ring_1(int wpc, bool inreg);
-ring_fn_t pick_ring_2(int wpc, bool inreg);
-ring_fn_t pick_ring_4(int wpc, bool inreg);
+ring_fn_t pick_ring_1(int wpc, bool inreg, bool strided);
+ring_fn_t pick_ring_2(int wpc, bool inreg, bool strided);
+ring_fn_t pick_ring_4(int wpc, bool inreg, bool strided);
 
 }  // namespace lsm_lif

@@ -2,8 +2,5 @@
 #include "lif_ring.h"
 
 namespace lsm_lif {
-ring_fn_t pick_ring_1(int wpc, bool inreg)
-{
-    return inreg ? pick_ring_wpc<1, true>(wpc) : pick_ring_wpc<1, false>(wpc);
-}
+ring_fn_t pick_ring_1(int wpc, bool inreg, bool strided) { return pick_ring<1>(wpc, inreg, strided); }
 }  // namespace lsm_lif

@@ -2,8 +2,5 @@
 #include "lif_ring.h"
 
 namespace lsm_lif {
-ring_fn_t pick_ring_2(int wpc, bool inreg)
-{
-    return inreg ? pick_ring_wpc<2, true>(wpc) : pick_ring_wpc<2, false>(wpc);
-}
+ring_fn_t pick_ring_2(int wpc, bool inreg, bool strided) { return pick_ring<2>(wpc, inreg, strided); }
 }  // namespace lsm_lif

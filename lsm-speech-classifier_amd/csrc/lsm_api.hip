@@ -2,6 +2,9 @@
 #include "lsm_common.h"
 
 #include <cstdarg>
+#include <mutex>
+#include <set>
+#include <utility>
 
 static thread_local char g_err[512] = "";
 
@@ -13,9 +16,21 @@ void lsm_set_error(const char *fmt, ...)
     va_end(ap);
 }
 
+void lsm_allow_big_lds(const void *kernel_fn)
+{
+    static std::mutex mu;
+    static std::set<std::pair<const void *, int>> done;
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    std::lock_guard<std::mutex> lk(mu);
+    if (done.insert({kernel_fn, dev}).second &&
+        hipFuncSetAttribute(kernel_fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+        (void)hipGetLastError();        // the launch that follows reports the failure
+}
+
 #define LSM_API extern "C" __attribute__((visibility("default")))
 
-LSM_API int lsm_version(void) { return 101; }   // 0.1.1: + lsm_raster_pack_bits / lsm_raster_unpack_bits
+LSM_API int lsm_version(void) { return 200; }   // 0.2.0: ring-row reservoir kernel, stats_out, lsm_reservoir_kernel_in_use
 
 LSM_API const char *lsm_last_error(void) { return g_err; }
 

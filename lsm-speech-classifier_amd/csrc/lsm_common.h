@@ -15,6 +15,11 @@
 
 void lsm_set_error(const char *fmt, ...);
 
+// Raise a kernel's dynamic-LDS limit to the CU's 160 KB, once per (function, device) for the life of the
+// process: launch functions then make no runtime call but the launch itself (hipGraph-capture safe, and two
+// threads launching the same kernel with different LDS sizes cannot lower each other's limit).
+void lsm_allow_big_lds(const void *kernel_fn);
+
 #define LSM_CHECK_HIP(expr)                                                         \
     do {                                                                            \
         hipError_t _e = (expr);                                                     \

@@ -6,9 +6,6 @@
 
 #include <algorithm>
 #include <cstring>
-#include <mutex>
-#include <set>
-#include <utility>
 #include <vector>
 
 using lsm_lif::LifArgs;
@@ -51,23 +48,13 @@ struct Variant {            // per waves-per-clip layout
 
 struct RingVariant {        // per waves-per-clip layout of the ring-row kernel (lif_ring.h)
     int wpc = 0, ql = 0, einw = 0;
+    bool strided = false;            // quad ownership: wave w owns quads w, w+wpc, ... (else w*ql .. w*ql+ql-1)
     uint32_t *rem_ptr = nullptr;     // (N*wpc + 1) first list entry of (row, wave)
     uint2 *rem = nullptr;            // synapses outside the ring window: {LDS byte offset, weight bits}
     float *leak = nullptr;
     int *oslot = nullptr;
     uint32_t *in_ent = nullptr;      // (wpc, einw) (channel << 16) | scratch word index
 };
-
-// Kernels that need more than 64 KB of dynamic LDS must raise the limit once per function and device; doing
-// it at launch time would put an API call that is not a launch into every call (and into graph captures).
-void allow_big_lds(const void *fn, int device)
-{
-    static std::mutex mu;
-    static std::set<std::pair<const void *, int>> done;
-    std::lock_guard<std::mutex> lk(mu);
-    if (done.insert({fn, device}).second)
-        (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-}
 
 }  // namespace
 
@@ -85,9 +72,10 @@ struct lsm_reservoir {
     float *band = nullptr;
     uint32_t band_pitch = 0;
     int band_h = 0, band_nq = 0, band_wsq = 0;
-    int mode = 0;           // 0 auto, 1 sparse (CSC scatter through LDS), 2 dense rows, 3 ring rows
+    int mode = 0;           // 0 auto, 1 sparse (CSC scatter through LDS), 2 dense rows, 3 ring rows,
+                            // 4 ring rows with contiguous quad ownership only (tests)
     Variant var[5];         // wpc = 1, 2, 4, 8, 16 (wpc == 0: not available)
-    RingVariant rvar[4];    // wpc = 2, 4, 8, 16
+    RingVariant rvar[8];    // wpc = 2, 4, 8, 16, contiguous [0..3] and strided [4..7] quad ownership
 };
 
 static int free_reservoir(lsm_reservoir *h)
@@ -300,20 +288,30 @@ int lsm_reservoir_create(lsm_reservoir **out, int num_neurons, int n_channels,
                 if ((rc = upload(&h->band, band))) { free_reservoir(h); return rc; }
                 h->band_pitch = pitch; h->band_h = H; h->band_nq = NQ; h->band_wsq = wsq;
                 const int rwpcs[4] = {2, 4, 8, 16};
-                for (int vi = 0; vi < 4; ++vi) {
-                    const int wpc = rwpcs[vi];
+                for (int vi = 0; vi < 8; ++vi) {
+                    const int wpc = rwpcs[vi & 3];
+                    const bool strided = vi >= 4;
                     int ql = 0;
-                    for (int cand : {1, 2, 4})
-                        if (!ql && wpc * cand * 256 >= N) ql = cand;
-                    // a wave must never hold both ends of a (wrapped) window: window quads + QL <= NQ
-                    if (!ql || wsq + ql > NQ) continue;
-                    const int npw = ql * 256, npad = npw * wpc;
+                    if (strided) {
+                        // every wave gets exactly one window quad per row: the residues mod wpc must survive the
+                        // ring's wrap (NQ % wpc == 0) and a window must not be wider than wpc quads
+                        if (NQ % wpc != 0 || wsq > wpc) continue;
+                        ql = NQ / wpc;
+                        if (ql != 1 && ql != 2 && ql != 4) continue;
+                    } else {
+                        for (int cand : {1, 2, 4})
+                            if (!ql && wpc * cand * 256 >= N) ql = cand;
+                        // a wave must never hold both ends of a (wrapped) window: window quads + QL <= NQ
+                        if (!ql || wsq + ql > NQ) continue;
+                    }
+                    const int npad = wpc * ql * 256;
+                    auto wave_of = [&](int i) { return lsm_lif::ring_wave_of_quad(i >> 8, ql, wpc, strided); };
                     std::vector<uint32_t> rptr((size_t)N * wpc + 1, 0u);
                     int emax = 0;
                     for (int j = 0; j < N; ++j)
                         for (int e = csc_ptr[j]; e < csc_ptr[j + 1]; ++e)
                             if (win_off(j, csc_post[e]) < 0)
-                                emax = std::max(emax, (int)++rptr[(size_t)j * wpc + csc_post[e] / npw + 1]);
+                                emax = std::max(emax, (int)++rptr[(size_t)j * wpc + wave_of(csc_post[e]) + 1]);
                     if (emax > 64) continue;                             // one lane per list entry
                     for (size_t q = 1; q < rptr.size(); ++q) rptr[q] += rptr[q - 1];
                     std::vector<uint2> rem(std::max<size_t>(1, rptr.back()));
@@ -324,8 +322,8 @@ int lsm_reservoir_create(lsm_reservoir **out, int num_neurons, int n_channels,
                             if (win_off(j, i) >= 0) continue;
                             uint32_t bits;
                             std::memcpy(&bits, &csc_w[e], 4);
-                            rem[fill[(size_t)j * wpc + i / npw]++] =
-                                make_uint2((uint32_t)lsm_lif::ring_scr_word(i, ql) * 4u, bits);
+                            rem[fill[(size_t)j * wpc + wave_of(i)]++] =
+                                make_uint2((uint32_t)lsm_lif::ring_scr_word(i, ql, wpc, strided) * 4u, bits);
                         }
                     std::vector<float> lk(npad, 0.0f);
                     std::vector<int> os(npad, -1);
@@ -335,8 +333,8 @@ int lsm_reservoir_create(lsm_reservoir **out, int num_neurons, int n_channels,
                     for (int c = 0; c < C; ++c)
                         for (int d = 0; d < in_fanout; ++d) {
                             const int tgt = in_tgt[(size_t)c * in_fanout + d];
-                            per[tgt / npw].push_back(((uint32_t)c << 16) |
-                                                     (uint32_t)lsm_lif::ring_scr_word(tgt, ql));
+                            per[wave_of(tgt)].push_back(((uint32_t)c << 16) |
+                                                        (uint32_t)lsm_lif::ring_scr_word(tgt, ql, wpc, strided));
                         }
                     size_t mx = 1;
                     for (auto &pp : per) mx = std::max(mx, pp.size());
@@ -350,7 +348,7 @@ int lsm_reservoir_create(lsm_reservoir **out, int num_neurons, int n_channels,
                         free_reservoir(h);
                         return rc;
                     }
-                    v.wpc = wpc; v.ql = ql; v.einw = einw;
+                    v.wpc = wpc; v.ql = ql; v.einw = einw; v.strided = strided;
                 }
             }
         }
@@ -371,8 +369,8 @@ extern "C" __attribute__((visibility("default")))
 int lsm_reservoir_set_kernel(lsm_reservoir *h, int mode)
 {
     LSM_REQUIRE(h != nullptr, "lsm_reservoir_set_kernel: null handle");
-    LSM_REQUIRE(mode >= 0 && mode <= 3, "mode must be 0 (auto), 1 (sparse), 2 (dense) or 3 (ring)");
-    LSM_REQUIRE(mode != 3 || has_ring(h), "this reservoir has no ring-row format (not ring-like, or too small)");
+    LSM_REQUIRE(mode >= 0 && mode <= 4, "mode must be 0 (auto), 1 (sparse), 2 (dense), 3 (ring) or 4 (ring, contiguous quads)");
+    LSM_REQUIRE(mode < 3 || has_ring(h), "this reservoir has no ring-row format (not ring-like, or too small)");
     LSM_REQUIRE(mode != 2 || h->wt != nullptr, "this reservoir has no dense row table");
     h->mode = mode;
     return LSM_OK;
@@ -412,21 +410,29 @@ static size_t ring_lds_bytes(const lsm_reservoir *h, const RingVariant &v, int T
     const size_t npad = (size_t)v.ql * 256 * v.wpc;
     const size_t cw = (size_t)(h->C + 31) / 32;
     return ((size_t)lsm_lif::RING_DUMP_WORDS + (size_t)v.wpc * 64 * lsm_lif::ring_stride(4 * v.ql)) * 4 +
-           2 * npad * 2 + 256 + (size_t)h->n_out * 16 + (size_t)T * cw * 4;
+           2 * npad * 2 + 512 + (size_t)h->n_out * 16 + (size_t)T * cw * 4;
 }
 
-// Ring layout for a batch: the requested waves per clip, else the layout with the most neurons per lane
-// (fewest per-row and per-wave overheads) that still gives a clip at least 4 waves.
+// Ring layout for a batch: the requested waves per clip, else the layout with the fewest waves that still gives
+// a clip at least 4 (every wave repeats the per-row work -- list hand-off, row parameters -- so fewer, fatter
+// waves win: N=4000, 1024 clips: 4 waves 10.1 ms, 8 waves 13.0-13.9 ms; N=8000, 512 clips: 8 waves 35.9 ms,
+// 16 waves 44.8 ms).  Between two layouts of equal wave count the strided quad ownership wins (N=8000, 8 waves:
+// 35.9 ms against 42.0 ms contiguous: one useful 1 KB window load per wave and row instead of four per wave in
+// two or three waves).
 static const RingVariant *choose_ring(const lsm_reservoir *h, int T, int requested)
 {
     const RingVariant *best = nullptr;
+    auto better = [](const RingVariant &v, const RingVariant &b) {
+        const bool v4 = v.wpc >= 4, b4 = b.wpc >= 4;
+        if (v4 != b4) return v4;
+        if (v.wpc != b.wpc) return v4 ? v.wpc < b.wpc : v.wpc > b.wpc;
+        return v.strided && !b.strided;
+    };
     for (const auto &v : h->rvar) {
         if (!v.wpc || ring_lds_bytes(h, v, T) > 160 * 1024) continue;
-        if (requested > 0) {
-            if (v.wpc == requested) return &v;
-            continue;
-        }
-        if (!best || (best->wpc < 4 && v.wpc >= 4)) best = &v;
+        if (v.strided && h->mode == 4) continue;
+        if (requested > 0 && v.wpc != requested) continue;
+        if (!best || better(v, *best)) best = &v;
     }
     return best;
 }
@@ -438,7 +444,7 @@ constexpr size_t RING_AUTO_MIN_DENSE_BYTES = (size_t)32 << 20;
 static bool want_ring(const lsm_reservoir *h)
 {
     if (!has_ring(h)) return false;
-    if (h->mode == 3) return true;
+    if (h->mode >= 3) return true;
     return h->mode == 0 && (size_t)h->N * (size_t)h->ld * 4 > RING_AUTO_MIN_DENSE_BYTES;
 }
 static bool use_dense(const lsm_reservoir *h) { return h->wt != nullptr && h->mode != 1; }
@@ -509,9 +515,9 @@ int lsm_reservoir_run(const lsm_reservoir *h, const uint8_t *spikes_u8, int n_cl
         LSM_REQUIRE(rv != nullptr, "no ring-row layout for waves_per_clip=%d (N=%d, T=%d)", waves_per_clip, h->N,
                     n_steps);
         const bool inreg = rv->einw <= IN_REG_SLOTS * 64;
-        lsm_lif::ring_fn_t rfn = rv->ql == 1   ? lsm_lif::pick_ring_1(rv->wpc, inreg)
-                                 : rv->ql == 2 ? lsm_lif::pick_ring_2(rv->wpc, inreg)
-                                               : lsm_lif::pick_ring_4(rv->wpc, inreg);
+        lsm_lif::ring_fn_t rfn = rv->ql == 1   ? lsm_lif::pick_ring_1(rv->wpc, inreg, rv->strided)
+                                 : rv->ql == 2 ? lsm_lif::pick_ring_2(rv->wpc, inreg, rv->strided)
+                                               : lsm_lif::pick_ring_4(rv->wpc, inreg, rv->strided);
         LSM_REQUIRE(rfn != nullptr, "no ring kernel for QL=%d WPC=%d", rv->ql, rv->wpc);
         lsm_lif::RingArgs r;
         r.N = h->N; r.C = h->C; r.T = n_steps; r.B = n_clips;
@@ -526,12 +532,12 @@ int lsm_reservoir_run(const lsm_reservoir *h, const uint8_t *spikes_u8, int n_cl
         r.features = features_out; r.spike_matrix = spike_matrix_out; r.v_trace = v_trace_out;
         r.stats = stats_out;
         const size_t lds = ring_lds_bytes(h, *rv, n_steps);
-        if (lds > 64 * 1024) allow_big_lds(reinterpret_cast<const void *>(rfn), h->device);
+        if (lds > 64 * 1024) lsm_allow_big_lds(reinterpret_cast<const void *>(rfn));
         hipLaunchKernelGGL(rfn, dim3(n_clips), dim3(rv->wpc * 64), lds, (hipStream_t)stream, r);
         LSM_CHECK_HIP(hipGetLastError());
         return LSM_OK;
     }
-    LSM_REQUIRE(h->mode != 3, "no ring-row layout for this reservoir");
+    LSM_REQUIRE(h->mode < 3, "no ring-row layout for this reservoir");
 
     const Variant *v = choose_variant(h, n_clips, n_steps, waves_per_clip);
     LSM_REQUIRE(v != nullptr, "no reservoir layout for waves_per_clip=%d (N=%d, T=%d)",
@@ -554,7 +560,7 @@ int lsm_reservoir_run(const lsm_reservoir *h, const uint8_t *spikes_u8, int n_cl
         d.stats = stats_out;
         const size_t dlds = dense_lds_bytes(h, *v, n_steps);
         LSM_REQUIRE(dlds <= 160 * 1024, "dense layout needs %zu bytes of LDS", dlds);
-        if (dlds > 64 * 1024) allow_big_lds(reinterpret_cast<const void *>(dfn), h->device);
+        if (dlds > 64 * 1024) lsm_allow_big_lds(reinterpret_cast<const void *>(dfn));
         hipLaunchKernelGGL(dfn, dim3(n_clips), dim3(v->wpc * 64), dlds, (hipStream_t)stream, d);
         LSM_CHECK_HIP(hipGetLastError());
         return LSM_OK;
@@ -576,7 +582,7 @@ int lsm_reservoir_run(const lsm_reservoir *h, const uint8_t *spikes_u8, int n_cl
     a.stats = stats_out;
 
     const size_t lds = lif_lds_bytes(h, *v, n_steps);
-    if (lds > 64 * 1024) allow_big_lds(reinterpret_cast<const void *>(fn), h->device);
+    if (lds > 64 * 1024) lsm_allow_big_lds(reinterpret_cast<const void *>(fn));
     hipLaunchKernelGGL(fn, dim3(n_clips), dim3(v->wpc * 64), lds, (hipStream_t)stream, a);
     LSM_CHECK_HIP(hipGetLastError());
     return LSM_OK;

@@ -37,6 +37,24 @@ def init(backend: str | None = None):
     return rank, local_rank, world
 
 
+def group_world():
+    """(rank, world_size) of the INITIALISED process group; (0, 1) when there is none -- so a caller that did
+    not go through init() never shards by a WORLD_SIZE it cannot gather over.  Raises when the launcher
+    environment announces several ranks but no group was initialised (the rows would silently be a shard)."""
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_rank(), dist.get_world_size()
+    if int(os.environ.get("WORLD_SIZE", "1")) > 1:
+        raise RuntimeError("WORLD_SIZE > 1 but torch.distributed is not initialised: call dist.init() first")
+    return 0, 1
+
+
+def finish():
+    """Leave the process group (end of main())."""
+    if dist.is_available() and dist.is_initialized():
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def shard_bounds(n: int, world: int):
     """Per-rank [lo, hi): contiguous blocks of ceil(n/world) clips (the last ones may be short or
     empty)."""

@@ -109,6 +109,20 @@ class HotPath:
         buf.copy_(audio, non_blocking=True)
         return buf
 
+    def prime(self, audio):
+        """One untimed step on EVERY stream of the rotation, then a synchronisation: each stream's first use
+        pays for its allocator pool (torch caches device memory per stream: the first `encode` on a stream
+        calls hipMalloc, which stalls every queue), for the first launch on its hardware queue and for the
+        kernels' one-off attribute calls.  Part of set-up; afterwards a step makes no runtime call but
+        launches and (host inputs) one asynchronous copy."""
+        self.fork_from_current()
+        events = self.reservoir_events
+        self.reservoir_events = []
+        for _ in range(self.n_streams):
+            self.submit(audio)
+        self.synchronize()
+        self.reservoir_events = events
+
     def fork_from_current(self):
         """Make every stream of the rotation wait for what the current stream has issued so far
         (inputs produced there, e.g. an upload or a reservoir build)."""

@@ -129,7 +129,8 @@ class SNN:
             "mean_spikes_per_neuron": total / self.num_neurons,
         }
 
-    KERNEL_MODES = {"auto": 0, "sparse": 1, "dense": 2, "ring": 3, "band": 3}    # 'band': round-1 name of 'ring'
+    # 'band': round-1 name of 'ring'; 'ring-contiguous': ring rows with contiguous quad ownership only (tests)
+    KERNEL_MODES = {"auto": 0, "sparse": 1, "dense": 2, "ring": 3, "band": 3, "ring-contiguous": 4}
 
     def set_kernel(self, mode: str = "auto"):
         """'auto' (register accumulation over dense presynaptic rows; over ring rows -- dense ring window

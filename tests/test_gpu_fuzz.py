@@ -58,7 +58,7 @@ def test_random_configurations_match_the_oracle(torch_cuda, oracle_c, seed, n_ca
         kernels = ["dense", "sparse"]
         try:
             net.set_kernel("ring")
-            kernels.append("ring")
+            kernels += ["ring", "ring-contiguous"]
         except _lib.LsmHipError:
             pass                                       # not ring-like enough, or too small, for ring rows
         for kernel in kernels:
@@ -70,7 +70,7 @@ def test_random_configurations_match_the_oracle(torch_cuda, oracle_c, seed, n_ca
                 except _lib.LsmHipError as e:          # a forced layout this reservoir does not have
                     assert "layout" in str(e) and wpc != 0, (case, str(e))
                     continue
-                ring_runs += kernel == "ring"
+                ring_runs += kernel == "ring-contiguous"
                 f, sm, vt = f.cpu().numpy(), sm.cpu().numpy(), vt.cpu().numpy()
                 for b in range(len(rasters)):
                     f_ref, sm_ref, vt_ref = oracle_c.lif_run(res, rasters[b], case["keys"], want_trace=True)
@@ -79,7 +79,7 @@ def test_random_configurations_match_the_oracle(torch_cuda, oracle_c, seed, n_ca
                     np.testing.assert_array_equal(vt[b], vt_ref, err_msg=msg)
                     np.testing.assert_array_equal(f[b], f_ref, err_msg=msg)
                     spikes += int(sm_ref.sum())
-    assert spikes > 10000                                  # the cases do exercise spiking networks
+    assert spikes > (10000 if n_hi <= 700 else 3000)       # the cases do exercise spiking networks
     assert n_lo < 700 or ring_runs >= n_cases              # the large cases do run the ring-row kernel
 
 

@@ -176,7 +176,7 @@ def _kernels(net):
     out = ["dense", "sparse"]
     try:
         net.set_kernel("ring")
-        out.insert(1, "ring")
+        out[1:1] = ["ring", "ring-contiguous"]       # both quad ownerships (the second: contiguous layouts only)
     except _lib.LsmHipError:
         pass
     net.set_kernel("auto")
@@ -313,7 +313,7 @@ def test_full_size_properties(torch_cuda, oracle_c):
     assert "ring" in kernels
     for kernel in kernels:                                               # kernels and layouts agree
         net.set_kernel(kernel)
-        for wpc in ((2, 4) if kernel == "ring" else (1, 4, 16)):         # (ring rows at N=1000: 2 or 4 waves)
+        for wpc in ((2, 4) if kernel.startswith("ring") else (1, 4, 16)):   # (ring rows at N=1000: 2 or 4 waves)
             fw, _, _ = net.run_batch(dev, waves_per_clip=wpc)
             np.testing.assert_array_equal(fw.cpu().numpy(), f)
     net.set_kernel("auto")
@@ -333,8 +333,54 @@ def test_large_reservoirs_match_oracle(torch_cuda, oracle_c, n, k, n_out, c, cli
     ref = oracle_c.lif_run_batch(res, rasters, keys, n_threads=clips)
     assert ref[:, :n_out].sum() > 0
     assert "ring" in _kernels(net)
-    for kernel in ("dense", "ring", "sparse"):           # 64 / 262 MB dense tables, ring rows, CSC scatter
+    for kernel in ("dense", "ring", "ring-contiguous", "sparse"):   # 64 / 262 MB dense tables, ring rows, CSC scatter
         net.set_kernel(kernel)
         for wpc in (0, 8):
             feats, _, _ = net.run_batch(rasters, keys, waves_per_clip=wpc)
             np.testing.assert_array_equal(feats.cpu().numpy(), ref, err_msg=f"{kernel} wpc {wpc}")
+
+
+def test_oracle_on_a_reservoir_it_did_not_build(torch_cuda, oracle_c):
+    """every reservoir the oracle ever saw came from the product's own build_reservoir.  Here the
+    wiring is drawn by the test itself -- a random directed graph (no ring, asymmetric, negative and positive
+    weights, a few neurons without inputs), random input map with channels feeding one neuron twice-removed,
+    random output subset, heterogeneous leak -- and handed to BOTH sides as plain arrays."""
+    from lsm_speech_classifier_amd import reservoir as R, snn, synth
+    rs = np.random.RandomState(2024)
+    n, c, t, n_out, fan = 333, 19, 160, 77, 5
+    dens = rs.rand(n, n) < 0.06
+    np.fill_diagonal(dens, False)
+    dens[:, [5, 100]] = False                                  # two neurons without outgoing synapses
+    dens[[7, 200], :] = False                                  # two without incoming ones
+    post, pre = np.nonzero(dens)                               # CSR by postsynaptic row, presynaptic ascending
+    w = (rs.randn(len(post)) * 0.08 + 0.05).astype(np.float32)
+    csr_ptr = np.zeros(n + 1, dtype=np.int32)
+    np.cumsum(np.bincount(post, minlength=n), out=csr_ptr[1:])
+    order = np.lexsort((post, pre))
+    csc_ptr = np.zeros(n + 1, dtype=np.int32)
+    np.cumsum(np.bincount(pre, minlength=n), out=csc_ptr[1:])
+    in_tgt = np.stack([np.sort(rs.choice(n, fan, replace=False)) for _ in range(c)]).astype(np.int32)
+    flat_c, flat_i = np.repeat(np.arange(c, dtype=np.int32), fan), in_tgt.reshape(-1)
+    o2 = np.lexsort((flat_c, flat_i))
+    in_ptr = np.zeros(n + 1, dtype=np.int32)
+    np.cumsum(np.bincount(flat_i, minlength=n), out=in_ptr[1:])
+    res = R.Reservoir(
+        num_neurons=n, n_channels=c, seed=-1, theta=np.float32(1.0), refractory_period=3, w_in=np.float32(0.3),
+        burst_isi_max=4, csr_ptr=csr_ptr, csr_pre=pre.astype(np.int32), csr_w=w,
+        csc_ptr=csc_ptr, csc_post=post[order].astype(np.int32), csc_w=np.ascontiguousarray(w[order]),
+        leak=np.clip(rs.normal(0.05, 0.03, n), 0, 1).astype(np.float32), in_fanout=fan, in_tgt=in_tgt,
+        in_ptr=in_ptr, in_chan=flat_c[o2].astype(np.int32), out_idx=np.sort(rs.choice(n, n_out, replace=False)).astype(np.int32))
+    net = snn.SNN(None, reservoir=res)
+    rasters = synth.bernoulli_raster(4, c, t, 0.25, seed=5)
+    assert "ring" not in _kernels(net)                         # nothing ring-like about this graph
+    total = 0
+    for kernel in ("dense", "sparse"):
+        net.set_kernel(kernel)
+        for wpc in (0, 1, 2, 4):
+            total += _check_against_oracle(net, rasters, oracle_c, wpc)
+    assert total > 2000                                        # it does spike (negative weights included)
+    from oracle import ref_numpy as O                          # and the two oracle restatements agree on it too
+    sm_np, vt_np = O.lif_run(res, rasters[0], want_trace=True)
+    _, sm_c, vt_c = oracle_c.lif_run(res, rasters[0], want_trace=True)
+    np.testing.assert_array_equal(sm_np, sm_c)
+    np.testing.assert_array_equal(vt_np, vt_c)

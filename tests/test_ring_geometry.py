@@ -35,24 +35,32 @@ def ring_tables(n, csc_ptr, csc_post, csc_w):
     return H, NQ, q0, nbytes, wsq, band, in_list
 
 
-def fetch_row(jj, wpc, ql, n, NQ, q0, nbytes, band):
-    """Device side: what the QL bounds-checked 16-byte loads of every wave return for row jj, as an array
-    over the padded neuron index (wpc*ql*256)."""
+def fetch_row(jj, wpc, ql, n, NQ, q0, nbytes, band, strided=False):
+    """Device side: what the bounds-checked 16-byte loads of every wave return for row jj, as an array over
+    the padded neuron index (wpc*ql*256).  Contiguous ownership: QL loads per wave; strided: one."""
     npad = wpc * ql * 256
     out = np.zeros(npad, dtype=np.float32)
     lane16 = np.arange(64, dtype=np.uint32) * 16
+
+    def load(byte_off, dest_quad):
+        voff = (lane16 + np.uint32(byte_off & 0xFFFFFFFF)) & np.uint32(0xFFFFFFFF)
+        for h in range(4):
+            o = voff.astype(np.uint64) + 4 * h
+            ok = o + 4 <= nbytes[jj]                          # per-dword range check of a raw buffer load
+            vals = np.where(ok, band[jj, np.minimum(o // 4, band.shape[1] - 1).astype(np.int64)], 0.0)
+            out[dest_quad * 256 + np.arange(64) * 4 + h] = vals
+
     for w in range(wpc):
-        g0 = w * ql
-        base = g0 - q0[jj] + NQ if g0 + ql - 1 < q0[jj] else g0 - q0[jj]
-        soff = np.uint32((base * 1024) & 0xFFFFFFFF)
-        for q in range(ql):
-            voff = (lane16 + soff + np.uint32(q * 1024)) & np.uint32(0xFFFFFFFF)
-            for h in range(4):
-                o = voff.astype(np.uint64) + 4 * h
-                ok = o + 4 <= nbytes[jj]                      # per-dword range check of a raw buffer load
-                vals = np.where(ok, band[jj, np.minimum(o // 4, band.shape[1] - 1).astype(np.int64)], 0.0)
-                idx = (w * ql + q) * 256 + np.arange(64) * 4 + h
-                out[idx] = vals
+        if strided:
+            ph = (w - q0[jj]) % wpc
+            gh = (q0[jj] + ph) % NQ
+            assert gh % wpc == w                              # the residue survives the wrap (NQ % wpc == 0)
+            load(ph * 1024, gh)                               # register quad gh // wpc of wave w = global quad gh
+        else:
+            g0 = w * ql
+            base = g0 - q0[jj] + NQ if g0 + ql - 1 < q0[jj] else g0 - q0[jj]
+            for q in range(ql):
+                load((base + q) * 1024, g0 + q)
     return out
 
 
@@ -75,20 +83,25 @@ def test_window_plus_list_reproduce_every_row(n, k, layouts):
     rows = np.unique(np.concatenate([np.arange(0, n, 37), np.arange(0, 260), np.arange(n - 260, n),
                                      np.arange(H - 3, H + 260), np.arange(n - H - 260, n - H + 3)])) % n
     for wpc, ql in layouts:
-        assert wpc * ql * 256 >= n and wsq + ql <= NQ                 # the constraint the builder enforces
-        npw = ql * 256
-        for jj in rows:
-            got = fetch_row(jj, wpc, ql, n, NQ, q0, nbytes, band)
-            e0, e1 = res.csc_ptr[jj], res.csc_ptr[jj + 1]
-            lst = in_list[e0:e1]
-            want = dense[jj].copy()
-            want[res.csc_post[e0:e1][lst]] = 0.0                     # those arrive through the list instead
-            # real neurons get exactly the window weights; a fetched value is never a synapse of the list
-            np.testing.assert_array_equal(got[:n], want, err_msg=f"row {jj} layout {(wpc, ql)}")
-            # list entries belong to the wave that owns the target
-            assert np.all(res.csc_post[e0:e1][lst] // npw < wpc)
-            # per (row, wave) the list fits one wavefront (one lane per entry)
-            assert np.bincount(res.csc_post[e0:e1][lst] // npw, minlength=wpc).max() <= 64
+        for strided in (False, True):
+            if strided:
+                if NQ % wpc or wsq > wpc or NQ // wpc not in (1, 2, 4):
+                    continue                                          # the builder does not offer it
+                ql_, owner = NQ // wpc, (lambda i: (i >> 8) % wpc)
+            else:
+                assert wpc * ql * 256 >= n and wsq + ql <= NQ         # the constraint the builder enforces
+                ql_, owner = ql, (lambda i: (i >> 8) // ql)
+            for jj in rows:
+                got = fetch_row(jj, wpc, ql_, n, NQ, q0, nbytes, band, strided)
+                e0, e1 = res.csc_ptr[jj], res.csc_ptr[jj + 1]
+                lst = in_list[e0:e1]
+                want = dense[jj].copy()
+                want[res.csc_post[e0:e1][lst]] = 0.0                 # those arrive through the list instead
+                # real neurons get exactly the window weights; a fetched value is never a synapse of the list
+                np.testing.assert_array_equal(got[:n], want, err_msg=f"row {jj} layout {(wpc, ql_, strided)}")
+                # list entries belong to the wave that owns the target; a (row, wave) list fits one wavefront
+                owners = owner(res.csc_post[e0:e1][lst])
+                assert np.all(owners < wpc) and np.bincount(owners, minlength=wpc).max() <= 64
 
 
 def test_scratch_word_layout_is_conflict_free():
@@ -98,12 +111,12 @@ def test_scratch_word_layout_is_conflict_free():
         sl = 4 * ql
         stride = 4 if sl == 4 else sl + 4
         for wpc in (2, 4, 8):
-            npw = sl * 64
-            i = np.arange(wpc * npw)
-            w, rem = i // npw, i % npw
-            word = 64 + (w * 64 + ((rem & 255) >> 2)) * stride + (rem >> 8) * 4 + (rem & 3)
-            assert len(np.unique(word)) == len(word) and word.min() >= 64
-            assert word.max() < 64 + wpc * 64 * stride <= 65535
+            i = np.arange(wpc * ql * 256)
+            g = i >> 8
+            for w, slot in ((g // ql, g % ql), (g % wpc, g // wpc)):          # contiguous, strided ownership
+                word = 64 + (w * 64 + ((i & 255) >> 2)) * stride + slot * 4 + (i & 3)
+                assert len(np.unique(word)) == len(word) and word.min() >= 64
+                assert word.max() < 64 + wpc * 64 * stride <= 65535
         lanes = np.arange(16)
         groups = ((lanes * stride) % 64) // 4
         assert len(np.unique(groups)) == 16
