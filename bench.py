@@ -342,7 +342,7 @@ def run_rank(args):
             achieved = per_clip * B / (lif_ms * 1e-3) / 1e9
             kname = {"dense": "lif_dense_kernel", "ring": "lif_ring_kernel", "sparse": "lif_kernel"}[net.kernel_in_use()]
             traffic = None
-            tfile = os.path.join(ROOT, "profiles", "lif_traffic.json")
+            tfile = os.environ.get("LSM_TRAFFIC_FILE") or os.path.join(ROOT, "profiles", "lif_traffic.json")
             if os.path.exists(tfile):
                 traffic = json.load(open(tfile)).get(f"{args.config}_B{B}_{net.kernel_in_use()}")
             line["roofline"] = {

@@ -5,11 +5,12 @@
 // structure.  The dense-row kernel moves N*4 bytes per spiking neuron and clip, 80 % of them zeros; at
 // N >= 4000 that is what bounds it (profiles/r01_big_traffic.json: 8-17x the algorithmic bytes).  A
 // Watts-Strogatz reservoir is a ring lattice with ~10 % rewired edges, so row j is stored as
-//   * its ring WINDOW: the weights onto the targets from the 256-aligned start of j-H .. j+H (circular),
-//     dense, in natural target order -- fetched with bounds-checked 16-byte buffer loads: a lane owns FOUR
-//     consecutive neurons of a 256-neuron "quad", and a quad the window does not reach is an out-of-range
-//     load that returns zeros without touching memory, so every wave runs the same straight-line code for
-//     every row (no per-slot index arithmetic, no branches around loads: the counted waits stay exact);
+//   * its ring WINDOW: the weights onto the targets j-H .. j+H (circular; from the 128-byte-aligned start), dense, in
+//     natural target order -- fetched with bounds-checked 16-byte buffer loads: a lane owns FOUR consecutive
+//     neurons of a 256-neuron "quad", and a lane or quad the window does not reach is an out-of-range load
+//     that returns zeros without touching memory, so every wave runs the same straight-line code for every
+//     row (no per-slot index arithmetic, no branches around loads: the counted waits stay exact) and only
+//     the window's own bytes are fetched;
 //   * a LIST of the synapses outside the window ("rewired"), per (row, wave), unpadded: {LDS byte offset of
 //     the target's scratch word, weight bits}.  One lane per entry PARKS the weight in the wave's scratch
 //     array, every lane reads back its own SL words (16-byte LDS reads), the parked words are cleared
@@ -65,7 +66,7 @@ struct RingArgs {
     uint32_t pitch;            // bytes between consecutive band rows
     float theta, w_in;
     const uint8_t *raster;     // (B, C, T) uint8
-    const float *band;         // (N, pitch/4): window of row j, quad-aligned start, natural target order
+    const float *band;         // (N, pitch/4): window of row j from its 32-aligned start, natural target order
     const uint32_t *rem_ptr;   // (N*WPC + 1) first list entry of (row j, wave w)
     const uint2 *rem;          // list entries {LDS byte offset of the target's scratch word, weight bits}
     const float *leak;         // (NPAD), neuron order
@@ -111,7 +112,13 @@ __global__ __launch_bounds__(WPC * 64) void lif_ring_kernel(const RingArgs a)
     constexpr int NT = WPC * 64;
     constexpr int STRIDE = ring_stride(SL);
     constexpr int WL = STRIDED ? 1 : QL;            // window loads per row and wave
-    constexpr int P = STRIDED ? 8 : (QL >= 4 ? 4 : 8);   // rows in flight (WL*4 + 2 registers each)
+#ifndef LSM_RING_P                                  // experiment switches: rows in flight (strided / contiguous)
+#define LSM_RING_P 4
+#endif
+#ifndef LSM_RING_PC
+#define LSM_RING_PC (QL >= 4 ? 4 : 8)
+#endif
+    constexpr int P = STRIDED ? LSM_RING_P : LSM_RING_PC;   // rows in flight (WL*4 + 2 registers each), even
     constexpr uint32_t RSRC_FLAGS = 0x00020000u;    // raw dword buffer, gfx9 family
     static_assert(NQP <= RING_MAX_QUADS, "at most 8192 neurons");
 
@@ -271,26 +278,30 @@ __global__ __launch_bounds__(WPC * 64) void lif_ring_kernel(const RingArgs a)
             const bool valid = l < total;
             const int jl = valid ? (int)list_prev[gsel * 256 + (l - pbase)] : 0;
             // ---- lane l: everything a wave needs to fetch row jl, computed for 64 rows at once ----
-            // window = targets from the 256-aligned start of jl-H up to jl+H (circular in N); in the stored row
-            // quad (q0 + p) mod NQ sits at position p.  Bytes of the row that exist: up to the window's end.
+            // The stored row starts at a4 = the 32-aligned (128-byte) start of jl-H and runs to jl+H along the PADDED ring
+            // (NQ*256 positions: neurons N..NQ*256-1 do not exist and hold zeros), so target i sits at byte
+            // ((i - a4) mod NQ*256)*4; only those bytes exist (num_records).  The quad at ring position p (global
+            // quad (q0 + p) mod NQ, q0 = a4 >> 8) therefore starts at byte (p*256 - (a4 & 255))*4: negative for
+            // the lanes of the first quad that lie in front of the window -- a huge unsigned offset, out of range.
             int a0 = jl - H; a0 += a0 < 0 ? N : 0;
             int b0 = jl + H; b0 -= b0 >= N ? N : 0;
-            const int q0 = a0 >> 8, q1 = b0 >> 8;
-            int p1 = q1 - q0; p1 += p1 < 0 ? NQ : 0;
-            const uint32_t p_nrec = valid ? (uint32_t)(p1 * 1024 + (((b0 & 255) >> 2) + 1) * 16) : 0u;
+            const int a4 = a0 & ~31;        // rows start on a 128-byte line: a wave's 1 KB load touches 8 lines, not 9
+            const int q0 = a4 >> 8, lead = a4 & 255;
+            int span = b0 - a4; span += span < 0 ? NQ * 256 : 0;
+            const uint32_t p_nrec = valid ? (uint32_t)(((span >> 2) + 1) * 16) : 0u;
             uint32_t p_soff;
             if (STRIDED) {
                 // the one window quad with residue w (NQ % WPC == 0): position (w - q0) mod WPC, global quad
-                // (q0 + position) mod NQ, my register quad = that / WPC -- carried in the offset's low bits
+                // (q0 + position) mod NQ, my register quad = that / WPC -- carried in the offset's low 4 bits
                 int ph = (w - q0) % WPC; ph += ph < 0 ? WPC : 0;
                 int gh = q0 + ph; gh -= gh >= NQ ? NQ : 0;
-                p_soff = (uint32_t)(ph * 1024) | (uint32_t)(gh / WPC);
+                p_soff = (uint32_t)((ph * 256 - lead) * 4) | (uint32_t)(gh / WPC);
             } else {
                 // position of my wave's first quad in that row: quads below q0 sit NQ further (wrapped window); a
                 // wave never holds both ends of a window (host: window quads + QL <= NQ)
                 const int g0 = w * QL;
                 const int base = (g0 + QL - 1 < q0) ? g0 - q0 + NQ : g0 - q0;
-                p_soff = (uint32_t)(base * 1024);                       // negative: wraps to > any num_records
+                p_soff = (uint32_t)((base * 256 - lead) * 4);           // negative: wraps to > any num_records
             }
             const uint64_t baddr = band_base + (uint64_t)(uint32_t)jl * a.pitch;
             const uint32_t p_blo = (uint32_t)baddr, p_bhi = (uint32_t)(baddr >> 32);
@@ -323,12 +334,12 @@ __global__ __launch_bounds__(WPC * 64) void lif_ring_kernel(const RingArgs a)
         const uint32_t rnrec = __builtin_amdgcn_readlane(p_rnrec, mm) & live;                   \
         const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc(                    \
             reinterpret_cast<void *>(((uint64_t)bhi << 32) | blo), 0, (int)nrec, RSRC_FLAGS);   \
-        qh[p] = soff & 1023u;                                                                   \
+        qh[p] = soff & 15u;                                                                     \
         _Pragma("unroll") for (int q = 0; q < WL; ++q) {                                        \
             /* the whole byte offset goes through the VGPR (opaque scalar: nothing is folded into the    */ \
             /* instruction's immediate), so a quad in front of the window is a huge unsigned offset and  */ \
             /* out of range whatever the address adder does with a carry                                  */ \
-            uint32_t so = (STRIDED ? (soff & ~1023u) : soff) + (uint32_t)q * 1024u;             \
+            uint32_t so = (STRIDED ? (soff & ~15u) : soff) + (uint32_t)q * 1024u;               \
             asm volatile("" : "+s"(so));                                                        \
             if (LSM_RING_ABLATE & 1) {                                                          \
                 wv[p][q] = (ring_f4){0.0f, 0.0f, 0.0f, 0.0f};                                   \
@@ -371,9 +382,14 @@ __global__ __launch_bounds__(WPC * 64) void lif_ring_kernel(const RingArgs a)
     {                                                                                           \
         _Pragma("unroll") for (int q = 0; q < QL; ++q) LSM_RING_ADD4(cin[q], got[g][q])         \
         if (STRIDED) {                                                                          \
-            /* the window quad lands in register quad qh[p] (wave-uniform): one arm of QL */     \
+            /* the window quad lands in register quad qh[p] (wave-uniform, and constant over long runs of */ \
+            /* the ascending rows): a real scalar branch into one of QL arms.  The empty asm keeps the    */ \
+            /* compiler from predicating all QL arms (it did: 16 v_pk_add + 16 v_cndmask per row)         */ \
             _Pragma("unroll") for (int q = 0; q < QL; ++q)                                      \
-                if (QL == 1 || qh[p] == (uint32_t)q) LSM_RING_ADD4(cin[q], wv[p][0])            \
+                if (QL == 1 || qh[p] == (uint32_t)q) {                                          \
+                    if (QL > 1) asm volatile("" ::: "memory");                                  \
+                    LSM_RING_ADD4(cin[q], wv[p][0])                                             \
+                }                                                                               \
         } else {                                                                                \
             _Pragma("unroll") for (int q = 0; q < QL; ++q) LSM_RING_ADD4(cin[q], wv[p][q])      \
         }                                                                                       \

@@ -244,9 +244,9 @@ int lsm_reservoir_create(lsm_reservoir **out, int num_neurons, int n_channels,
         h->ld = ldmax;
     }
     // Ring rows for ring-like graphs (lif_ring.h): window half-width H = half the mean out-degree (k/2 of a
-    // small-world graph).  Row j covers the targets from the 256-aligned start of (j-H) mod N up to (j+H) mod N;
-    // quad (q0 + p) mod NQ of the ring sits at position p of the stored row.  Offered when the plain window
-    // holds most of the synapses and is a real saving (< half a row).
+    // small-world graph).  Row j covers the targets from the 32-aligned start of (j-H) mod N up to (j+H) mod N
+    // along the ring padded to NQ quads of 256.  Offered when the plain window holds most of the synapses and is
+    // a real saving (< half a row).
     {
         const int H = (int)((nnz / (size_t)N + 1) / 2);
         const int wd = 2 * H + 1;
@@ -259,25 +259,28 @@ int lsm_reservoir_create(lsm_reservoir **out, int num_neurons, int n_channels,
                 inside += q < wd;
             }
         if (H >= 1 && 2 * wd <= N && NQ >= 2 && nnz > 0 && inside * 10 >= nnz * 6) {
-            // geometry per row: q0 (first quad), bytes that exist (up to the window's end, 16-byte granules)
-            std::vector<int> q0v(N), nbytes(N);
-            int wsq = 0;
+            // geometry per row: a4 (32-aligned first target of the window: 128 bytes), bytes that exist (up to the window's
+            // end along the padded ring of NQ*256 positions, 16-byte granules), quads the window touches
+            const int NP = NQ * 256;
+            std::vector<int> a4v(N), nbytes(N);
+            int wsq = 0, maxb = 0;
             for (int j = 0; j < N; ++j) {
                 int a0 = j - H; a0 += a0 < 0 ? N : 0;
                 int b0 = j + H; b0 -= b0 >= N ? N : 0;
-                const int q0 = a0 >> 8, q1 = b0 >> 8;
-                int p1 = q1 - q0; p1 += p1 < 0 ? NQ : 0;
-                q0v[j] = q0;
-                nbytes[j] = p1 * 1024 + (((b0 & 255) >> 2) + 1) * 16;
-                wsq = std::max(wsq, p1 + 1);
+                const int a4 = a0 & ~31;
+                int span = b0 - a4; span += span < 0 ? NP : 0;
+                a4v[j] = a4;
+                nbytes[j] = ((span >> 2) + 1) * 16;
+                maxb = std::max(maxb, nbytes[j]);
+                wsq = std::max(wsq, (((a4 & 255) + span) >> 8) + 1);
             }
             if (wsq < NQ) {
-                const uint32_t pitch = (uint32_t)wsq * 1024u;
+                const uint32_t pitch = ((uint32_t)maxb + 127u) & ~127u;     // every row starts on a 128-byte line
                 std::vector<float> band((size_t)N * (pitch / 4), 0.0f);
                 // byte offset of synapse (j -> i) in row j, or -1 when i lies outside the stored window
                 auto win_off = [&](int j, int i) -> long {
-                    int p = (i >> 8) - q0v[j]; p += p < 0 ? NQ : 0;
-                    const long off = (long)p * 1024 + (long)(i & 255) * 4;
+                    int p = i - a4v[j]; p += p < 0 ? NP : 0;
+                    const long off = (long)p * 4;
                     return off < nbytes[j] ? off : -1;
                 };
                 for (int j = 0; j < N; ++j)

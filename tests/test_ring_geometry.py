@@ -14,35 +14,36 @@ def ring_tables(n, csc_ptr, csc_post, csc_w):
     nnz = int(csc_ptr[-1])
     H = (nnz // n + 1) // 2
     NQ = (n + 255) // 256
+    NP = NQ * 256                                       # the ring padded to whole quads
     j = np.arange(n)
-    a0 = (j - H) % n
+    a4 = ((j - H) % n) & ~31                            # 32-aligned (128-byte) first target of the stored row
     b0 = (j + H) % n
-    q0 = a0 >> 8
-    p1 = ((b0 >> 8) - q0) % NQ
-    nbytes = p1 * 1024 + (((b0 & 255) >> 2) + 1) * 16
-    wsq = int(p1.max()) + 1
-    pitch = wsq * 1024
+    span = (b0 - a4) % NP
+    nbytes = ((span >> 2) + 1) * 16
+    wsq = int(((((a4 & 255) + span) >> 8) + 1).max())
+    pitch = (int(nbytes.max()) + 127) & ~127
     band = np.zeros((n, pitch // 4), dtype=np.float32)
     in_list = np.zeros(nnz, dtype=bool)
     for jj in range(n):
         e0, e1 = csc_ptr[jj], csc_ptr[jj + 1]
         i = csc_post[e0:e1]
-        p = ((i >> 8) - q0[jj]) % NQ
-        off = p * 1024 + (i & 255) * 4
+        off = ((i - a4[jj]) % NP) * 4
         win = off < nbytes[jj]
         band[jj, off[win] // 4] = csc_w[e0:e1][win]
         in_list[e0:e1] = ~win
-    return H, NQ, q0, nbytes, wsq, band, in_list
+    return H, NQ, a4, nbytes, wsq, band, in_list
 
 
-def fetch_row(jj, wpc, ql, n, NQ, q0, nbytes, band, strided=False):
+def fetch_row(jj, wpc, ql, n, NQ, a4, nbytes, band, strided=False):
     """Device side: what the bounds-checked 16-byte loads of every wave return for row jj, as an array over
     the padded neuron index (wpc*ql*256).  Contiguous ownership: QL loads per wave; strided: one."""
     npad = wpc * ql * 256
     out = np.zeros(npad, dtype=np.float32)
     lane16 = np.arange(64, dtype=np.uint32) * 16
+    q0, lead = int(a4[jj]) >> 8, int(a4[jj]) & 255
 
-    def load(byte_off, dest_quad):
+    def load(ring_pos, dest_quad):                        # the quad at ring position p starts at byte (p*256-lead)*4
+        byte_off = (ring_pos * 256 - lead) * 4
         voff = (lane16 + np.uint32(byte_off & 0xFFFFFFFF)) & np.uint32(0xFFFFFFFF)
         for h in range(4):
             o = voff.astype(np.uint64) + 4 * h
@@ -52,15 +53,15 @@ def fetch_row(jj, wpc, ql, n, NQ, q0, nbytes, band, strided=False):
 
     for w in range(wpc):
         if strided:
-            ph = (w - q0[jj]) % wpc
-            gh = (q0[jj] + ph) % NQ
+            ph = (w - q0) % wpc
+            gh = (q0 + ph) % NQ
             assert gh % wpc == w                              # the residue survives the wrap (NQ % wpc == 0)
-            load(ph * 1024, gh)                               # register quad gh // wpc of wave w = global quad gh
+            load(ph, gh)                                      # register quad gh // wpc of wave w = global quad gh
         else:
             g0 = w * ql
-            base = g0 - q0[jj] + NQ if g0 + ql - 1 < q0[jj] else g0 - q0[jj]
+            base = g0 - q0 + NQ if g0 + ql - 1 < q0 else g0 - q0
             for q in range(ql):
-                load((base + q) * 1024, g0 + q)
+                load(base + q, g0 + q)
     return out
 
 
@@ -74,7 +75,7 @@ def fetch_row(jj, wpc, ql, n, NQ, q0, nbytes, band, strided=False):
 def test_window_plus_list_reproduce_every_row(n, k, layouts):
     p = R.SimulationParams(num_neurons=n, num_output_neurons=n // 2, small_world_graph_k=k, mean_weight=0.01)
     res = R.build_reservoir(p, 16)
-    H, NQ, q0, nbytes, wsq, band, in_list = ring_tables(n, res.csc_ptr, res.csc_post, res.csc_w)
+    H, NQ, a4, nbytes, wsq, band, in_list = ring_tables(n, res.csc_ptr, res.csc_post, res.csc_w)
     assert H == k // 2 and 2 * (2 * H + 1) <= n and wsq < NQ
     assert in_list.mean() < 0.12                                     # ~10 % of a small-world graph is rewired
     dense = np.zeros((n, n), dtype=np.float32)
@@ -92,7 +93,7 @@ def test_window_plus_list_reproduce_every_row(n, k, layouts):
                 assert wpc * ql * 256 >= n and wsq + ql <= NQ         # the constraint the builder enforces
                 ql_, owner = ql, (lambda i: (i >> 8) // ql)
             for jj in rows:
-                got = fetch_row(jj, wpc, ql_, n, NQ, q0, nbytes, band, strided)
+                got = fetch_row(jj, wpc, ql_, n, NQ, a4, nbytes, band, strided)
                 e0, e1 = res.csc_ptr[jj], res.csc_ptr[jj + 1]
                 lst = in_list[e0:e1]
                 want = dense[jj].copy()
