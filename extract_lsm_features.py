@@ -73,7 +73,6 @@ def extract_all_features(lsm, spike_data, feature_keys, desc=""):
     if hasattr(lsm, "run_batch"):
         import torch
         from lsm_speech_classifier_amd import dist as lsm_dist
-        from lsm_speech_classifier_amd.snn import FEATURE_KEYS
         rank, world = lsm_dist.group_world()         # the initialised process group, else a single process
         n = len(spike_data)
         lo, hi = lsm_dist.shard_range(n, rank, world) if world > 1 else (0, n)
@@ -84,9 +83,9 @@ def extract_all_features(lsm, spike_data, feature_keys, desc=""):
             feats, _, _ = lsm.run_batch(np.ascontiguousarray(spike_data[a:min(hi, a + RUN_BATCH)]),
                                         feature_keys)
             rows.append(feats)
-        n_feat = len([k for k in feature_keys if k in FEATURE_KEYS]) * lsm.num_output_neurons   # as run_batch filters
-        local = torch.cat(rows) if rows else torch.empty((0, n_feat), dtype=torch.float32,
-                                                         device=lsm.device)
+        # an empty shard still takes part in the gather: its row width comes from an empty launch-free call,
+        # so it is whatever run_batch makes of these keys (unknown keys are dropped there)
+        local = torch.cat(rows) if rows else lsm.run_batch(np.ascontiguousarray(spike_data[:0]), feature_keys)[0]
         return lsm_dist.gather_rows(local, n).cpu().numpy()
     rows = []
     for sample in spike_data:

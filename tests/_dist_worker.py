@@ -21,14 +21,25 @@ class FakeLsm:
         return torch.cat([base * (k + 1) for k in range(len(feature_keys))], dim=1), None, None
 
 
+def real_lsm():
+    """The real reservoir on cuda:0 (tests/test_gpu_hotpath.py: two ranks share the card, gloo moves the rows)."""
+    from lsm_speech_classifier_amd.snn import SNN, SimulationParams
+    return SNN(SimulationParams(num_neurons=300, num_output_neurons=100, small_world_graph_k=30, mean_weight=0.05),
+               n_channels=4, device="cuda:0")
+
+
 def main():
     out_dir, n = sys.argv[1], int(sys.argv[2])
+    gpu = len(sys.argv) > 3 and sys.argv[3] == "gpu"
     from lsm_speech_classifier_amd import dist as lsm_dist
     import extract_lsm_features as ex
     rank, _, world = lsm_dist.init("gloo")
     rs = np.random.RandomState(1)
-    clips = (rs.rand(n, 4, 6) < 0.4).astype(np.uint8)
-    feats = ex.extract_all_features(FakeLsm(), clips, ["a", "b"], "")
+    clips = (rs.rand(n, 4, 6 if not gpu else 120) < 0.4).astype(np.uint8)
+    if gpu:
+        feats = ex.extract_all_features(real_lsm(), clips, ["spike_counts", "mean_isi"], "")
+    else:
+        feats = ex.extract_all_features(FakeLsm(), clips, ["a", "b"], "")
     lo, hi = lsm_dist.shard_range(n, rank, world)
     w = lsm_dist.broadcast_float(3.25 + rank, 0)
     np.savez(os.path.join(out_dir, f"rank{rank}.npz"), feats=feats, lo=lo, hi=hi, w=w)

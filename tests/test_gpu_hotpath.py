@@ -73,3 +73,30 @@ def test_bench_spawns_two_ranks_on_a_shared_gpu():
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["config"]["clips_per_gpu"] == 64 and "all-gather" in d["config"]["sharding"]
     assert abs(d["value"] - 2 * 64 / (d["ms_per_step"] * 1e-3)) / d["value"] < 1e-3
+
+
+@pytest.mark.parametrize("world,n", [(2, 9), (3, 2)])          # uneven shards; 3 ranks for 2 clips: an empty shard
+def test_extract_all_features_two_ranks_real_reservoir(tmp_path, world, n):
+    """extract_all_features under a launcher with the REAL reservoir: the ranks share cuda:0, the
+    feature rows travel through gloo, every rank ends with all rows in dataset order = the single-process run."""
+    import socket
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import _dist_worker
+    import extract_lsm_features as ex
+    rs = np.random.RandomState(1)
+    clips = (rs.rand(n, 4, 120) < 0.4).astype(np.uint8)
+    single = ex.extract_all_features(_dist_worker.real_lsm(), clips, ["spike_counts", "mean_isi"], "")
+    assert single.shape == (n, 200) and single.sum() > 0
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for rank in range(world):
+        env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "_dist_worker.py"), str(tmp_path),
+                                       str(n), "gpu"], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+    outs = [p.communicate(timeout=300)[0] for p in procs]
+    assert all(p.returncode == 0 for p in procs), "\n".join(outs)
+    for rank in range(world):
+        np.testing.assert_array_equal(np.load(tmp_path / f"rank{rank}.npz")["feats"], single)

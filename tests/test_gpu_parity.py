@@ -185,9 +185,11 @@ def _kernels(net):
 
 def _check_against_oracle(net, rasters, oracle_c, wpc, keys=None):
     from lsm_speech_classifier_amd import _lib
+    import torch
+    stats = torch.full((len(rasters), 2), -1, dtype=torch.int32, device="cuda")
     try:
         feats, sm, vt = net.run_batch(rasters, keys, want_spike_matrix=True, want_v_trace=True,
-                                      waves_per_clip=wpc)
+                                      waves_per_clip=wpc, stats_out=stats)
     except _lib.LsmHipError as e:
         if "no ring-row layout" in str(e):                   # the ring kernel has 1-3 layouts per reservoir
             return 1
@@ -199,6 +201,8 @@ def _check_against_oracle(net, rasters, oracle_c, wpc, keys=None):
         np.testing.assert_array_equal(sm[b], sm_ref, err_msg=f"spike matrix clip {b} wpc {wpc}")
         np.testing.assert_array_equal(vt[b], vt_ref, err_msg=f"membrane trace clip {b} wpc {wpc}")
         np.testing.assert_array_equal(feats[b], f_ref, err_msg=f"features clip {b} wpc {wpc}")
+        per = sm_ref.sum(axis=0)                                   # the in-kernel health statistics (§8f-3)
+        assert stats[b].tolist() == [int(np.count_nonzero(per)), int(per.sum())], f"stats clip {b} wpc {wpc}"
         total += int(sm_ref.sum())
     return total
 
