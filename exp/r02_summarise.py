@@ -39,7 +39,7 @@ def short(name):
 
 for src, dst in (("bench_driver.json", "r02_bench_driver_first.json"), ("bench_default.json", "r02_bench_default.json"),
                  ("bench_serial.json", "r02_bench_serial.json")):
-    line = last_json_line(os.path.join(SRC, src))
+    line = last_json_line(os.path.join(SRC, src)) if os.path.exists(os.path.join(SRC, src)) else None
     if line:
         json.dump(line, open(os.path.join(DST, dst), "w"), indent=1)
 for d, dst in (("stats_driver", "r02_kernel_stats_driver.csv"), ("stats", "r02_kernel_stats.csv"),

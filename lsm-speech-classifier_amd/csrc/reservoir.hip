@@ -416,20 +416,19 @@ static size_t ring_lds_bytes(const lsm_reservoir *h, const RingVariant &v, int T
            2 * npad * 2 + 512 + (size_t)h->n_out * 16 + (size_t)T * cw * 4;
 }
 
-// Ring layout for a batch: the requested waves per clip, else the layout with the fewest waves that still gives
-// a clip at least 4 (every wave repeats the per-row work -- list hand-off, row parameters -- so fewer, fatter
-// waves win: N=4000, 1024 clips: 4 waves 10.1 ms, 8 waves 13.0-13.9 ms; N=8000, 512 clips: 8 waves 35.9 ms,
-// 16 waves 44.8 ms).  Between two layouts of equal wave count the strided quad ownership wins (N=8000, 8 waves:
-// 35.9 ms against 42.0 ms contiguous: one useful 1 KB window load per wave and row instead of four per wave in
-// two or three waves).
+// Ring layout for a batch: the requested waves per clip, else a strided layout when the reservoir has one (every
+// wave gets one useful 1 KB window load per row: N=8000, 8 waves: 29.0 ms against 42.0 ms contiguous; N=4000:
+// 8 waves strided 9.7 ms against 4 fat waves contiguous 10.2 ms), and within a kind the layout with the fewest
+// waves that still gives a clip at least 4 (every wave repeats the per-row work -- list hand-off, row
+// parameters: N=8000 strided, 8 waves 29.0 ms, 16 waves 36.8 ms; N=4000 contiguous, 4 waves 10.2 ms, 8 waves 13.9 ms).
 static const RingVariant *choose_ring(const lsm_reservoir *h, int T, int requested)
 {
     const RingVariant *best = nullptr;
     auto better = [](const RingVariant &v, const RingVariant &b) {
+        if (v.strided != b.strided) return v.strided;
         const bool v4 = v.wpc >= 4, b4 = b.wpc >= 4;
         if (v4 != b4) return v4;
-        if (v.wpc != b.wpc) return v4 ? v.wpc < b.wpc : v.wpc > b.wpc;
-        return v.strided && !b.strided;
+        return v4 ? v.wpc < b.wpc : v.wpc > b.wpc;
     };
     for (const auto &v : h->rvar) {
         if (!v.wpc || ring_lds_bytes(h, v, T) > 160 * 1024) continue;
