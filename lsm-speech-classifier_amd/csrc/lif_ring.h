@@ -182,11 +182,11 @@ __global__ __launch_bounds__(WPC * 64) void lif_ring_kernel(const RingArgs a)
         const int o[4] = {o4.x, o4.y, o4.z, o4.w};
 #pragma unroll
         for (int h = 0; h < 4; ++h) {
-            v[4 * q + h] = 0.0f;
-            // padding neurons (i >= N) get a NaN leak: their potential is NaN from the first step on, the
+            // padding neurons (i >= N) start with a NaN potential: it stays NaN through every update, the
             // threshold test is false for ever -- a window that wraps past the ring's end may deliver weights
             // of real quads to them, and they must never fire
-            lam[4 * q + h] = (i0 + h) < N ? l[h] : __builtin_nanf("");
+            v[4 * q + h] = (i0 + h) < N ? 0.0f : __builtin_nanf("");
+            lam[4 * q + h] = l[h];
             oref[4 * q + h] = (uint32_t)(o[h] + 1);
         }
     }

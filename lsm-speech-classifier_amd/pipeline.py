@@ -49,12 +49,14 @@ class HotPath:
 
     def __init__(self, fe, net, feature_keys=None, streams: int = DEFAULT_STREAMS,
                  waves_per_clip: int | None = None, time_reservoir: bool = False):
-        if fe.device != net.device:
+        def norm(d):      # a tensor's device always carries its index, `torch.device("cuda")` does not
+            return d if d.index is not None or d.type != "cuda" else torch.device("cuda", torch.cuda.current_device())
+        if norm(fe.device) != norm(net.device):
             raise ValueError(f"front end on {fe.device}, reservoir on {net.device}")
         if fe.n_channels != net.n_channels:
             raise ValueError(f"front end has {fe.n_channels} channels, reservoir expects {net.n_channels}")
         self.fe, self.net = fe, net
-        self.device = fe.device
+        self.device = norm(fe.device)     # so that a device-resident batch is recognised as such (not copied again)
         self.feature_keys = feature_keys
         self.n_streams = max(1, int(streams))
         # inside the rotation the reservoir launch shares the chip: let the library pick for that case
