@@ -388,3 +388,24 @@ def test_oracle_on_a_reservoir_it_did_not_build(torch_cuda, oracle_c):
     _, sm_c, vt_c = oracle_c.lif_run(res, rasters[0], want_trace=True)
     np.testing.assert_array_equal(sm_np, sm_c)
     np.testing.assert_array_equal(vt_np, vt_c)
+
+
+@pytest.mark.parametrize("n,k,c,t", [(1024, 120, 40, 120), (2048, 300, 96, 100), (4096, 300, 200, 80),
+                                     (8192, 400, 256, 60), (6144, 500, 64, 60)])
+def test_ring_rows_at_quad_multiples(torch_cuda, oracle_c, n, k, c, t):
+    """Sizes whose quad count is a multiple of the wave counts (strided quad ownership exists, except at 6144 =
+    24 quads) and N = 8192, the largest reservoir: no padding neurons at all, windows that wrap exactly at a quad
+    boundary, input maps beyond 128 channels.  Both ring ownerships, every layout the reservoir offers."""
+    from lsm_speech_classifier_amd import snn, synth
+    rasters = synth.bernoulli_raster(2, c, t, 0.25, seed=n + k)
+    res = _reservoir(n, k, n // 3, c, rasters)
+    net = snn.SNN(None, reservoir=res)
+    assert "ring" in _kernels(net)
+    ran = 0
+    for kernel in ("ring", "ring-contiguous", "dense"):
+        net.set_kernel(kernel)
+        for wpc in (0, 2, 4, 8, 16):
+            if kernel == "dense" and wpc not in (0, 16):
+                continue
+            ran += _check_against_oracle(net, rasters, oracle_c, wpc) > 1
+    assert ran >= 4
