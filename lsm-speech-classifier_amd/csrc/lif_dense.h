@@ -176,6 +176,11 @@ __global__ __launch_bounds__(WPC * 64) void lif_dense_kernel(const DenseArgs a)
         }
     };
 
+#if LSM_STAMP                         // diagnostic builds only: per-phase s_memtime sums of wave 0 of each clip
+    unsigned long long st_sum[8] = {0, 0, 0, 0, 0, 0, 0, 0}, st_last;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_last)::"memory");
+    const unsigned long long st_loop0 = st_last, st_real0 = __builtin_amdgcn_s_memrealtime();
+#endif
     for (int t = 0; t < T; ++t) {
         // The step list read and the row fetch are the latency-critical part of a step: they issue at
         // raised priority so that waves of other kernels sharing the SIMD (the float64 filterbank in the
@@ -242,6 +247,7 @@ __global__ __launch_bounds__(WPC * 64) void lif_dense_kernel(const DenseArgs a)
                 if (G > 14 && todo) { LSM_LD(14)
                 if (G > 15 && todo) { LSM_LD(15) } } } } } } } } } } } } } } }
 #undef LSM_LD
+                STAMP(1);
                 if (!drove) {                     // the input counts fill the load latency
                     input_drive(t);
                     drove = true;
@@ -267,12 +273,14 @@ __global__ __launch_bounds__(WPC * 64) void lif_dense_kernel(const DenseArgs a)
                 if (n8 > 14) { LSM_ADD(14)
                 if (n8 > 15) { LSM_ADD(15) } } } } } } } } } } } } } } }
 #undef LSM_ADD
+                STAMP(2);
             }
         };
 
         // ---- spiking neurons of step t-1 ----
         const uint32_t pcnt = wcnt[prv * 16 + lane / R];            // spikes of producer wave lane/R
         const uint32_t jfix = flist[prv * 64 + lane];               // its (lane%R)-th spiking neuron
+        STAMP(0);
         // a producer with more than R spikes does not fit its fixed region: the counts themselves say so
         if (__ballot(pcnt > (uint32_t)R) == 0ull) {
             add_rows(__ballot((uint32_t)(lane % R) < pcnt), jfix);
@@ -329,6 +337,7 @@ __global__ __launch_bounds__(WPC * 64) void lif_dense_kernel(const DenseArgs a)
             bal[r] = __ballot(fire);
             any_fire |= bal[r];
         }
+        STAMP(3);
         int nspk = 0;
         if (any_fire != 0ull) {                  // one branch per wave and step
 #pragma unroll
@@ -372,8 +381,16 @@ __global__ __launch_bounds__(WPC * 64) void lif_dense_kernel(const DenseArgs a)
                 }
             }
         }
+        STAMP(4);
         if (!(LSM_ABLATE & 4)) __syncthreads();
+        STAMP(5);
     }
+#if LSM_STAMP
+    st_sum[6] = st_last - st_loop0;                                   // shader cycles in the step loop
+    st_sum[7] = __builtin_amdgcn_s_memrealtime() - st_real0;          // 100 MHz ticks in the step loop
+    if (tid == 0)
+        for (int k = 0; k < 8; ++k) atomicAdd(&g_lif_stamps[k], st_sum[k]);
+#endif
 
     // ---- epilogue: health statistics (/root/reference/extract_lsm_features.py:119-133 derives them from the
     //      (T, N) spike matrix; here they come from one flag per neuron and one count per wave), then
@@ -445,5 +462,8 @@ dense_fn_t pick_dense_sl(int sl, int wpc)
 dense_fn_t pick_dense_0(int sl, int wpc);      // lif_dense_0.hip (INMODE 0: entries from global memory)
 dense_fn_t pick_dense_1(int sl, int wpc);      // lif_dense_1.hip (INMODE 1: entries in registers)
 dense_fn_t pick_dense_2(int sl, int wpc);      // lif_dense_2.hip (INMODE 2: channel masks, C <= 128, SL <= 4)
+#if LSM_STAMP
+int read_lif_stamps_d2(unsigned long long *o, int r);   // stamps of the INMODE-2 unit (the cfg2 kernel)
+#endif
 
 }  // namespace lsm_lif

@@ -3,4 +3,7 @@
 
 namespace lsm_lif {
 dense_fn_t pick_dense_2(int sl, int wpc) { return pick_dense_sl<2>(sl, wpc); }
+#if LSM_STAMP
+LSM_DEFINE_STAMP_READER(read_lif_stamps_d2)
+#endif
 }  // namespace lsm_lif

@@ -627,9 +627,9 @@ int lsm_debug_lif_stamps(unsigned long long *out8, int reset)
 {
     for (int k = 0; k < 8; ++k) out8[k] = 0;
 #if LSM_STAMP
-    for (int q = 0; q < 4; ++q) {
+    for (int q = 0; q < 5; ++q) {                 // the four sparse-kernel units + the dense kernel's INMODE-2 unit
         unsigned long long part[8];
-        int rc = lsm_lif::read_lif_stamps(q, part, reset);
+        int rc = q < 4 ? lsm_lif::read_lif_stamps(q, part, reset) : lsm_lif::read_lif_stamps_d2(part, reset);
         if (rc) return rc;
         for (int k = 0; k < 8; ++k) out8[k] += part[k];
     }
