@@ -63,6 +63,7 @@ __global__ __launch_bounds__(WPC * 64) void lif_dense_kernel(const DenseArgs a)
     constexpr int NT = WPC * 64;
     constexpr int R = 64 / WPC;            // fixed-region list entries per producer wave
     constexpr int G = SL == 1 ? 16 : 32 / SL;   // rows in flight per group (<= 32 registers of weights)
+    constexpr bool FEATREG = SL <= 4;           // feature accumulators in registers (4 per neuron) instead of LDS
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint32_t *icnt = reinterpret_cast<uint32_t *>(smem);                              // NPAD
@@ -148,6 +149,9 @@ __global__ __launch_bounds__(WPC * 64) void lif_dense_kernel(const DenseArgs a)
     const char *wt_bytes = reinterpret_cast<const char *>(a.wt);
     const uint32_t ld_bytes = (uint32_t)a.ld * 4u;
     const uint32_t lane_off = (uint32_t)(w * NPW + lane) * 4u;
+    uint4 fr[FEATREG ? SL : 1];        // FEATREG: {n | bursts << 16, first | last << 16, sum t, sum isi^2} per neuron
+#pragma unroll
+    for (int r = 0; r < (FEATREG ? SL : 1); ++r) fr[r] = make_uint4(0, 0, 0, 0);
     uint32_t hf = 0u;                  // bit r: my neuron r fired at least once (stats)
     uint32_t tot_spk = 0u;             // spikes of my wave (stats)
     __syncthreads();
@@ -349,8 +353,11 @@ __global__ __launch_bounds__(WPC * 64) void lif_dense_kernel(const DenseArgs a)
                     list_cur[rank] = me;
                     if (rank < R) flist[cur * 64 + w * R + rank] = me;
                     hf |= 1u << r;
-                    if (os[r] >= 0 && !(LSM_ABLATE & 8)) {
-                        uint4 f = feat[os[r]];
+                    if ((FEATREG || os[r] >= 0) && !(LSM_ABLATE & 8)) {
+                        // FEATREG: the accumulators of EVERY neuron of the lane sit in registers (no LDS round
+                        // trip in the fire path, which all other waves wait for at the barrier); they are parked
+                        // in the LDS array once, after the last step
+                        uint4 f = FEATREG ? fr[r] : feat[os[r]];
                         uint32_t n = f.x & 0xFFFFu, bursts = f.x >> 16;
                         uint32_t first = f.y & 0xFFFFu, last = f.y >> 16;
                         const uint32_t isi = (uint32_t)t - last;
@@ -362,7 +369,8 @@ __global__ __launch_bounds__(WPC * 64) void lif_dense_kernel(const DenseArgs a)
                         f.z += (uint32_t)t;
                         f.x = n | (bursts << 16);
                         f.y = first | (last << 16);
-                        feat[os[r]] = f;
+                        if (FEATREG) fr[r] = f;
+                        else feat[os[r]] = f;
                     }
                 }
                 nspk += __popcll(bal[r]);
@@ -392,6 +400,12 @@ __global__ __launch_bounds__(WPC * 64) void lif_dense_kernel(const DenseArgs a)
         for (int k = 0; k < 8; ++k) atomicAdd(&g_lif_stamps[k], st_sum[k]);
 #endif
 
+    if (FEATREG) {
+#pragma unroll
+        for (int r = 0; r < SL; ++r)
+            if (os[r] >= 0) feat[os[r]] = fr[r];
+        __syncthreads();
+    }
     // ---- epilogue: health statistics (/root/reference/extract_lsm_features.py:119-133 derives them from the
     //      (T, N) spike matrix; here they come from one flag per neuron and one count per wave), then
     //      SPEC.md §4 features from the integer accumulators (float64, then float32) ----
