@@ -26,6 +26,20 @@
 #endif                      // drive, 4 = no step barrier, 8 = no feature updates, 16 = no loads (adds kept),
                             // 32 = rows folded onto the first 256 (1 MB footprint), 64 = non-temporal raster reads
 
+// Row fetch, same-box A/B at 128 filters / 1000 neurons / 256 clips (profiles/r02_dense_row_chain_ab.txt):
+// LSM_DENSE_BUF=1 issues the row loads as MUBUF `buffer_load ... offen` with the row offset as scalar operand
+// (no per-row vector address add) - and the launch takes 0.60 ms instead of 0.53: with eight waves of a CU
+// issuing dword gathers, buffer loads run at 3/4 of the rate of global loads (exp/ubench_vmem.hip,
+// profiles/r02_ubench_global_vs_buffer_loads.txt).  Kept as a switch so that the measurement can be repeated.
+// LSM_DENSE_BITSET: clear the consumed list bit with one s_bitset0_b64 instead of the three-instruction
+// `todo &= todo - 1`; with the row offsets premultiplied once per 64 entries a row costs 9 instructions per
+// wave instead of 12 (0.532 -> 0.519 ms).
+#ifndef LSM_DENSE_BUF
+#define LSM_DENSE_BUF 0
+#endif
+#ifndef LSM_DENSE_BITSET
+#define LSM_DENSE_BITSET 1
+#endif
 namespace lsm_lif {
 
 struct DenseArgs {
@@ -146,7 +160,10 @@ __global__ __launch_bounds__(WPC * 64) void lif_dense_kernel(const DenseArgs a)
     const bool trace = a.spike_matrix != nullptr || a.v_trace != nullptr;
     // weight of presynaptic j onto my target r: byte offset j*ld*4 (scalar, 32 bits are enough:
     // N*ld*4 <= 2^28 for N <= 8192) + my lane's byte offset (vector) + r*256 (immediate)
+    // (a buffer load takes the row offset as its scalar operand: no per-row vector address arithmetic)
     const char *wt_bytes = reinterpret_cast<const char *>(a.wt);
+    const __amdgpu_buffer_rsrc_t wt_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float *>(a.wt), 0, (int)((uint32_t)N * (uint32_t)a.ld * 4u), 0x00020000);
     const uint32_t ld_bytes = (uint32_t)a.ld * 4u;
     const uint32_t lane_off = (uint32_t)(w * NPW + lane) * 4u;
     uint4 fr[FEATREG ? SL : 1];        // FEATREG: {n | bursts << 16, first | last << 16, sum t, sum isi^2} per neuron
@@ -218,19 +235,24 @@ __global__ __launch_bounds__(WPC * 64) void lif_dense_kernel(const DenseArgs a)
         auto add_rows = [&](unsigned long long todo, uint32_t jl) {
             if (LSM_ABLATE & 1) todo = 0ull;
             if (LSM_ABLATE & 4) jl = min(jl, (uint32_t)(N - 1));
+            // entry -> byte offset of its row, once per 64 entries (N*ld*4 <= 2^28 for N <= 8192)
+            const uint32_t jo = ((LSM_ABLATE & 32) ? (jl & 255u) : jl) * ld_bytes;
             while (todo != 0ull) {
                 const int n8 = min((int)__builtin_popcountll(todo), G);
                 float wv[16][SL];                   // only the first G rows are ever live
 #define LSM_LD(k)                                                                   \
     {                                                                               \
         const int sk = __builtin_ctzll(todo);                                       \
-        todo &= todo - 1ull;                                                        \
-        const uint32_t j = __builtin_amdgcn_readlane(jl, sk);                       \
+        const uint32_t j = __builtin_amdgcn_readlane(jo, sk);                       \
+        if (LSM_DENSE_BITSET) asm volatile("s_bitset0_b64 %0, %1" : "+s"(todo) : "s"(sk)); \
+        else todo &= todo - 1ull;                                                   \
         {                                                                           \
-            const char *rowp = wt_bytes + (((LSM_ABLATE & 32) ? (j & 255u) : j) * ld_bytes); \
+            const int so = (int)j;                                                  \
             _Pragma("unroll") for (int r = 0; r < SL; ++r)                          \
                 wv[k][r] = (LSM_ABLATE & 16) ? __uint_as_float(j + r)               \
-                         : *reinterpret_cast<const float *>(rowp + lane_off + r * 256); \
+                         : LSM_DENSE_BUF ? __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(    \
+                               wt_rsrc, (int)lane_off + r * 256, so, 0))            \
+                         : *reinterpret_cast<const float *>(wt_bytes + j + lane_off + r * 256); \
         }                                                                           \
     }
                 // the load chain tests the remaining-entries mask itself (one scalar 64-bit compare per row)
