@@ -12,10 +12,16 @@
 //     row (no per-slot index arithmetic, no branches around loads: the counted waits stay exact) and only
 //     the window's own bytes are fetched;
 //   * a LIST of the synapses outside the window ("rewired"), per (row, wave), unpadded: {LDS byte offset of
-//     the target's scratch word, weight bits}.  One lane per entry PARKS the weight in the wave's scratch
-//     array, every lane reads back its own SL words (16-byte LDS reads), the parked words are cleared
-//     again.  LDS executes a wave's instructions in order, so park / read / clear need no waits between
-//     them, and idle lanes park into a 64-word dump region instead of being masked off.
+//     the target's accumulator word, weight bits}, one lane per entry.
+// The float32 accumulators of a step live in LDS, one word per neuron in neuron order, and belong to the wave
+// that owns the neuron.  A row is applied by read-modify-write: the wave reads the 1 KB accumulator quad under
+// its window load (16 bytes per lane) and the words its list entries point at, adds, writes the quad back and
+// then the list words (LDS runs a wave's instructions in order: the next row's reads see these writes; a lane
+// without an entry got {0, 0} from the bounds check and adds 0 to its own word of a 64-word dump region, so
+// nothing is masked off).  A row costs a wave ~30 instructions whatever the number of neurons it owns; the
+// first version of this kernel kept the sums in registers and handed the list weights over through an LDS
+// scratch array that every lane read back in full for every row (~60 instructions per row and wave at 16
+// neurons per lane, 32 KB of LDS reads per row at N = 8000) -- see DESIGN.md 4b.
 // A target receives row j's weight from the window or from the list, never both, the other term is +0.0
 // (x + 0 = x in float32 for every x the sum can take), and rows are applied in ascending j: every target's
 // float32 sum keeps the oracle's order and is bit-identical.
@@ -32,8 +38,8 @@
 // per quad; quad order = ascending neuron order under both ownerships, so lane l of a consumer finds the
 // l-th spiking neuron of the clip by a prefix over the quad counts.
 //
-// Rows are pipelined: P = 4 rows' loads are in flight while the oldest is applied (2, 6, 8 and 12 are all slower:
-// profiles/r02_ring_rows_in_flight.txt), and the LDS hand-off of row m+1 is issued before the adds of row m.
+// Rows are pipelined: P rows' loads are in flight while the oldest is applied, and the accumulator reads of row
+// m+1 are issued right after the writes of row m, ahead of the scalar work that launches row m+P.
 #pragma once
 #include "lif_kernel.h"
 
@@ -69,10 +75,10 @@ struct RingArgs {
     const uint8_t *raster;     // (B, C, T) uint8
     const float *band;         // (N, pitch/4): window of row j from its 32-aligned start, natural target order
     const uint32_t *rem_ptr;   // (N*WPC + 1) first list entry of (row j, wave w)
-    const uint2 *rem;          // list entries {LDS byte offset of the target's scratch word, weight bits}
+    const uint2 *rem;          // list entries {LDS byte offset of the target's accumulator, weight bits}
     const float *leak;         // (NPAD), neuron order
     const int *oslot;          // (NPAD) output slot or -1, neuron order
-    const uint32_t *in_ent;    // (WPC, EinW) (channel << 16) | scratch WORD index of the target, 0xFFFFFFFF = padding
+    const uint32_t *in_ent;    // (WPC, EinW) (channel << 16) | target neuron, 0xFFFFFFFF = padding
     int n_keys;
     int key_ids[8];
     float *features;           // (B, n_keys * n_out)
@@ -85,22 +91,18 @@ typedef float ring_f4 __attribute__((ext_vector_type(4)));
 typedef uint32_t ring_u4 __attribute__((ext_vector_type(4)));
 typedef uint32_t ring_u2 __attribute__((ext_vector_type(2)));
 
-constexpr int RING_DUMP_WORDS = 64;                 // LDS words 0..63: where idle lanes park
+constexpr int RING_DUMP_WORDS = 64;                 // LDS words 0..63 of an array: where idle lanes add their zeros
 constexpr int RING_MAX_QUADS = 32;                  // 8192 neurons
-__host__ __device__ constexpr int ring_stride(int sl) { return sl == 4 ? 4 : sl + 4; }   // scratch words per lane:
-                                                    // 16-byte reads of 16 lanes then fall on 16 distinct 4-bank groups
 
 // owner of quad g in a layout: (wave, register quad)
 __host__ __device__ inline int ring_wave_of_quad(int g, int ql, int wpc, bool strided) { return strided ? g % wpc : g / ql; }
 __host__ __device__ inline int ring_slot_of_quad(int g, int ql, int wpc, bool strided) { return strided ? g / wpc : g % ql; }
 
-// scratch WORD index (from the start of LDS) of neuron i
-__host__ __device__ inline int ring_scr_word(int i, int ql, int wpc, bool strided)
-{
-    const int g = i >> 8, lane = (i & 255) >> 2, h = i & 3;
-    return RING_DUMP_WORDS + (ring_wave_of_quad(g, ql, wpc, strided) * 64 + lane) * ring_stride(4 * ql) +
-           ring_slot_of_quad(g, ql, wpc, strided) * 4 + h;
-}
+// accumulator WORD index (from the start of LDS) of neuron i: neuron order behind the dump words, so a lane's four
+// neurons are one 16-byte word group and a quad is 1 KB (conflict-free 16-byte accesses of 64 lanes)
+__host__ __device__ inline int ring_acc_word(int i) { return RING_DUMP_WORDS + i; }
+// input counts: 16 bits per neuron, two neurons per word, behind their own dump words
+__host__ __device__ inline int ring_cnt_word(int i) { return RING_DUMP_WORDS + (i >> 1); }
 
 // QL: quads (256 neurons, 4 per lane) per wave; WPC: waves per clip; INREG: the wave's input-map entries sit
 // in registers (else they stream from global memory every step); STRIDED: quad ownership (see above).
@@ -111,7 +113,6 @@ __global__ __launch_bounds__(WPC * 64) void lif_ring_kernel(const RingArgs a)
     constexpr int NQP = QL * WPC;                   // quads of the padded layout (<= 32)
     constexpr int NPAD = NQP * 256;
     constexpr int NT = WPC * 64;
-    constexpr int STRIDE = ring_stride(SL);
     constexpr int WL = STRIDED ? 1 : QL;            // window loads per row and wave
 #ifndef LSM_RING_P                                  // experiment switches: rows in flight (strided / contiguous)
 #define LSM_RING_P 4
@@ -124,8 +125,9 @@ __global__ __launch_bounds__(WPC * 64) void lif_ring_kernel(const RingArgs a)
     static_assert(NQP <= RING_MAX_QUADS, "at most 8192 neurons");
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    uint32_t *scr = reinterpret_cast<uint32_t *>(smem);                               // dump + WPC*64*STRIDE
-    uint16_t *wlist = reinterpret_cast<uint16_t *>(scr + RING_DUMP_WORDS + WPC * 64 * STRIDE);   // 2*NPAD: 256 per quad
+    float *acc = reinterpret_cast<float *>(smem);                                     // dump + NPAD accumulators
+    uint32_t *cnt = reinterpret_cast<uint32_t *>(acc + RING_DUMP_WORDS + NPAD);       // dump + NPAD/2 input counts
+    uint16_t *wlist = reinterpret_cast<uint16_t *>(cnt + RING_DUMP_WORDS + NPAD / 2); // 2*NPAD: 256 per quad
     uint32_t *wcnt = reinterpret_cast<uint32_t *>(wlist + 2 * NPAD);                  // 2*32 quad counts + 2 stats
     uint4 *feat = reinterpret_cast<uint4 *>(wcnt + 128);                              // n_out
     uint32_t *bits = reinterpret_cast<uint32_t *>(feat + a.n_out);                    // T*CW
@@ -139,7 +141,7 @@ __global__ __launch_bounds__(WPC * 64) void lif_ring_kernel(const RingArgs a)
 #define LSM_RING_GQ(q) (STRIDED ? (q) * WPC + w : w * QL + (q))
 
     // ---- prologue: zero LDS state, bit-pack the clip's raster time-major ----
-    for (int i = tid; i < RING_DUMP_WORDS + WPC * 64 * STRIDE; i += NT) scr[i] = 0u;
+    for (int i = tid; i < 2 * RING_DUMP_WORDS + NPAD + NPAD / 2; i += NT) reinterpret_cast<uint32_t *>(smem)[i] = 0u;
     for (int i = tid; i < 128; i += NT) wcnt[i] = 0u;
     for (int i = tid; i < a.n_out; i += NT) feat[i] = make_uint4(0, 0, 0, 0);
     for (int i = tid; i < T * CW; i += NT) bits[i] = 0u;
@@ -192,7 +194,7 @@ __global__ __launch_bounds__(WPC * 64) void lif_ring_kernel(const RingArgs a)
         }
     }
     const uint32_t ref_set = (uint32_t)a.refractory << 16;
-    uint32_t in_word[IN_REG_SLOTS], in_mask[IN_REG_SLOTS], in_tgt[IN_REG_SLOTS];
+    uint32_t in_word[IN_REG_SLOTS], in_mask[IN_REG_SLOTS], in_tgt[IN_REG_SLOTS], in_inc[IN_REG_SLOTS];
     if (INREG) {
 #pragma unroll
         for (int q = 0; q < IN_REG_SLOTS; ++q) {
@@ -200,15 +202,19 @@ __global__ __launch_bounds__(WPC * 64) void lif_ring_kernel(const RingArgs a)
             const uint32_t x = e < a.EinW ? a.in_ent[(size_t)w * a.EinW + e] : 0xFFFFFFFFu;
             const bool ok = x != 0xFFFFFFFFu;
             const uint32_t c = x >> 16;
+            const uint32_t i = x & 0xFFFFu;                             // target neuron
             in_word[q] = ok ? (c >> 5) : 0u;
             in_mask[q] = ok ? (1u << (c & 31)) : 0u;
-            in_tgt[q] = ok ? (x & 0xFFFFu) : (uint32_t)lane;          // padding: own dump word, adds 0
+            in_inc[q] = 1u << ((i & 1u) * 16u);                         // the target's half of its count word
+            in_tgt[q] = ok ? (uint32_t)ring_cnt_word((int)i) : (uint32_t)lane;   // padding: own dump word, adds 0
         }
     }
     const float theta = a.theta, w_in = a.w_in;
     const uint32_t *my_ent = a.in_ent + (size_t)w * a.EinW;
     const bool trace = a.spike_matrix != nullptr || a.v_trace != nullptr;
-    uint32_t *myscr = scr + RING_DUMP_WORDS + (w * 64 + lane) * STRIDE;      // my SL scratch words
+    // byte address (from the start of LDS) of my four accumulators of global quad g: acc_b + g*1024
+    const uint32_t acc_b = (uint32_t)RING_DUMP_WORDS * 4u + (uint32_t)lane * 16u;
+    const uint32_t cnt_b = (uint32_t)(2 * RING_DUMP_WORDS + NPAD) * 4u + (uint32_t)lane * 8u;   // my four counts: + g*512
     const uint32_t lane4 = (uint32_t)lane * 4u, lane8 = (uint32_t)lane * 8u, lane16 = (uint32_t)lane * 16u;
     const uint64_t band_base = reinterpret_cast<uint64_t>(a.band);
     const uint64_t rem_base = reinterpret_cast<uint64_t>(a.rem);
@@ -224,8 +230,8 @@ __global__ __launch_bounds__(WPC * 64) void lif_ring_kernel(const RingArgs a)
             for (int q = 0; q < IN_REG_SLOTS; q += 2) {
                 if (q * 64 < a.EinW) {
                     const uint32_t w0 = row[in_word[q]], w1 = row[in_word[q + 1]];
-                    atomicAdd(scr + in_tgt[q], (w0 & in_mask[q]) ? 1u : 0u);
-                    if ((q + 1) * 64 < a.EinW) atomicAdd(scr + in_tgt[q + 1], (w1 & in_mask[q + 1]) ? 1u : 0u);
+                    atomicAdd(cnt + in_tgt[q], (w0 & in_mask[q]) ? in_inc[q] : 0u);
+                    if ((q + 1) * 64 < a.EinW) atomicAdd(cnt + in_tgt[q + 1], (w1 & in_mask[q + 1]) ? in_inc[q + 1] : 0u);
                 }
             }
         } else {
@@ -244,7 +250,9 @@ __global__ __launch_bounds__(WPC * 64) void lif_ring_kernel(const RingArgs a)
                         const bool ok = x[u] != 0xFFFFFFFFu;
                         const uint32_t c = ok ? (x[u] >> 16) : 0u;
                         const uint32_t bit = (row[c >> 5] >> (c & 31)) & 1u;
-                        atomicAdd(scr + (ok ? (x[u] & 0xFFFFu) : (uint32_t)lane), ok ? bit : 0u);
+                        const uint32_t i = x[u] & 0xFFFFu;              // target neuron: 16-bit count in word i/2
+                        atomicAdd(cnt + (ok ? (uint32_t)ring_cnt_word((int)i) : (uint32_t)lane),
+                                  ok ? bit << ((i & 1u) * 16u) : 0u);
                     }
                 }
             }
@@ -255,10 +263,6 @@ __global__ __launch_bounds__(WPC * 64) void lif_ring_kernel(const RingArgs a)
         const int cur = t & 1, prv = cur ^ 1;
         const uint16_t *list_prev = wlist + prv * NPAD;
         uint16_t *list_cur = wlist + cur * NPAD;
-
-        ring_f4 cin[QL];
-#pragma unroll
-        for (int q = 0; q < QL; ++q) cin[q] = (ring_f4){0.0f, 0.0f, 0.0f, 0.0f};
 
         // ---- spiking neurons of step t-1: prefix of the per-quad counts, lane l <- l-th neuron ----
         const uint32_t cv = wcnt[prv * 32 + (lane & 31)];
@@ -306,23 +310,24 @@ __global__ __launch_bounds__(WPC * 64) void lif_ring_kernel(const RingArgs a)
             }
             const uint64_t baddr = band_base + (uint64_t)(uint32_t)jl * a.pitch;
             const uint32_t p_blo = (uint32_t)baddr, p_bhi = (uint32_t)(baddr >> 32);
-            uint32_t r0 = 0u, r1 = 0u;
-            if (valid) {
-                r0 = a.rem_ptr[jl * WPC + w];
-                r1 = a.rem_ptr[jl * WPC + w + 1];
-            }
+            // (lanes past the chunk's end look at row 0: a valid address, and `live` voids their rows below --
+            //  no branch around these loads)
+            const uint32_t r0 = a.rem_ptr[jl * WPC + w];
+            const uint32_t r1 = a.rem_ptr[jl * WPC + w + 1];
             const uint64_t raddr = rem_base + (uint64_t)r0 * 8u;
             const uint32_t p_rlo = (uint32_t)raddr, p_rhi = (uint32_t)(raddr >> 32);
             const uint32_t p_rnrec = (r1 - r0) * 8u;
             const int n = (int)min(64u, total - l0);
-
             ring_f4 wv[P][WL];
             ring_u2 re[P];
-            ring_f4 got[2][QL];
+            ring_f4 old[WL];                     // accumulators under the window load of the row being applied
+            float oldl;                          // accumulator under my list entry of that row
+            uint32_t wa[WL];                     // their LDS byte addresses
+            uint32_t pa;
             uint32_t qh[P];                      // STRIDED: register quad the window load of buffer p belongs to
-            // LOAD(p, m): issue the loads of the chunk's row m (a scalar) into buffer p.  Rows >= n do not
+            // LOADW / LOADL(p, m): issue the window / list load of the chunk's row m (a scalar) into buffer p.  Rows >= n do not
             // exist: their num_records is 0, every load is out of range and returns zeros without traffic.
-#define LSM_RING_LOAD(p, m)                                                                     \
+#define LSM_RING_LOADW(p, m)                                                                    \
     {                                                                                           \
         const int mm = (m) & 63;                                                                \
         const uint32_t live = (uint32_t) - (int)((m) < n);                                      \
@@ -330,9 +335,6 @@ __global__ __launch_bounds__(WPC * 64) void lif_ring_kernel(const RingArgs a)
         const uint32_t bhi = __builtin_amdgcn_readlane(p_bhi, mm);                              \
         const uint32_t nrec = __builtin_amdgcn_readlane(p_nrec, mm) & live;                     \
         const uint32_t soff = __builtin_amdgcn_readlane(p_soff, mm);                            \
-        const uint32_t rlo = __builtin_amdgcn_readlane(p_rlo, mm);                              \
-        const uint32_t rhi = __builtin_amdgcn_readlane(p_rhi, mm);                              \
-        const uint32_t rnrec = __builtin_amdgcn_readlane(p_rnrec, mm) & live;                   \
         const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc(                    \
             reinterpret_cast<void *>(((uint64_t)bhi << 32) | blo), 0, (int)nrec, RSRC_FLAGS);   \
         qh[p] = soff & 15u;                                                                     \
@@ -350,68 +352,70 @@ __global__ __launch_bounds__(WPC * 64) void lif_ring_kernel(const RingArgs a)
                                      __uint_as_float(x.z), __uint_as_float(x.w)};               \
             }                                                                                   \
         }                                                                                       \
+    }
+#define LSM_RING_LOADL(p, m)                                                                    \
+    {                                                                                           \
+        const int mm = (m) & 63;                                                                \
+        const uint32_t live = (uint32_t) - (int)((m) < n);                                      \
+        const uint32_t rlo = __builtin_amdgcn_readlane(p_rlo, mm);                              \
+        const uint32_t rhi = __builtin_amdgcn_readlane(p_rhi, mm);                              \
+        const uint32_t rnrec = __builtin_amdgcn_readlane(p_rnrec, mm) & live;                   \
         const __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc(                    \
             reinterpret_cast<void *>(((uint64_t)rhi << 32) | rlo), 0, (int)rnrec, RSRC_FLAGS);  \
         if (LSM_RING_ABLATE & 8) re[p] = (ring_u2){0u, 0u};                                     \
         else re[p] = __builtin_amdgcn_raw_buffer_load_b64(rr, (int)lane8, 0, 0);                \
         __builtin_amdgcn_sched_barrier(0);                                                      \
     }
-            // PARK(p, g): the rewired synapses of the row in buffer p reach their targets through the scratch
-            // array: park, every lane reads its SL words into got[g], clear -- LDS runs a wave's instructions
-            // in order, so nothing waits in between.  Lanes without an entry got {0, 0} from the bounds check
-            // and park a zero into their own dump word.
-#define LSM_RING_PARK(p, g)                                                                     \
+            // READ(p): fetch the accumulators the row in buffer p adds to: the quad(s) under its window load and
+            // the word under my list entry (a lane without one got {0, 0} from the bounds check: its own dump word).
+#define LSM_RING_READ(p)                                                                        \
     {                                                                                           \
-        if (LSM_RING_ABLATE & 2) {                                                              \
-            _Pragma("unroll") for (int q = 0; q < QL; ++q)                                      \
-                got[g][q] = (ring_f4){__uint_as_float(re[p].x), 0.0f, 0.0f, __uint_as_float(re[p].y)}; \
-        } else {                                                                                \
-            const uint32_t pa = max(re[p].x, lane4);                                            \
+        _Pragma("unroll") for (int q = 0; q < WL; ++q) {                                        \
+            wa[q] = acc_b + (uint32_t)(STRIDED ? (qh[p] * WPC + w) : (w * QL + q)) * 1024u;     \
+            old[q] = *reinterpret_cast<const ring_f4 *>(smem + wa[q]);                          \
+        }                                                                                       \
+        pa = max(re[p].x, lane4);                                                               \
+        oldl = *reinterpret_cast<const float *>(smem + pa);                                     \
+        __builtin_amdgcn_sched_barrier(0);                                                      \
+    }
+            // APPLY(p): add row p and write back -- the window quad first, the list word after it (a list target
+            // may sit in a part of that quad the window does not cover: its word then holds old + 0 from the
+            // quad write and receives old + weight from the list write, in that order).  Rows are applied in
+            // ascending j = the order of these calls; LDS keeps a wave's accesses in program order.
+#define LSM_RING_APPLY(p)                                                                       \
+    {                                                                                           \
+        if (!(LSM_RING_ABLATE & 2)) {                                                           \
+            _Pragma("unroll") for (int q = 0; q < WL; ++q) {                                    \
+                LSM_RING_ADD4(old[q], wv[p][q])                                                 \
+                *reinterpret_cast<ring_f4 *>(smem + wa[q]) = old[q];                            \
+            }                                                                                   \
             asm volatile("" ::: "memory");                                                      \
-            *reinterpret_cast<uint32_t *>(smem + pa) = re[p].y;                                 \
-            asm volatile("" ::: "memory");                                                      \
-            _Pragma("unroll") for (int q = 0; q < QL; ++q)                                      \
-                got[g][q] = *reinterpret_cast<const ring_f4 *>(myscr + 4 * q);                  \
-            asm volatile("" ::: "memory");                                                      \
-            *reinterpret_cast<uint32_t *>(smem + pa) = 0u;                                      \
+            *reinterpret_cast<float *>(smem + pa) = oldl + __uint_as_float(re[p].y);            \
             asm volatile("" ::: "memory");                                                      \
         }                                                                                       \
         __builtin_amdgcn_sched_barrier(0);                                                      \
     }
-            // ADD(p, g): row p's contributions, ascending-j order of the rows = order of these calls
-#define LSM_RING_ADD(p, g)                                                                      \
-    {                                                                                           \
-        _Pragma("unroll") for (int q = 0; q < QL; ++q) LSM_RING_ADD4(cin[q], got[g][q])         \
-        if (STRIDED) {                                                                          \
-            /* the window quad lands in register quad qh[p] (wave-uniform, and constant over long runs of */ \
-            /* the ascending rows): a real scalar branch into one of QL arms.  The empty asm keeps the    */ \
-            /* compiler from predicating all QL arms (it did: 16 v_pk_add + 16 v_cndmask per row)         */ \
-            _Pragma("unroll") for (int q = 0; q < QL; ++q)                                      \
-                if (QL == 1 || qh[p] == (uint32_t)q) {                                          \
-                    if (QL > 1) asm volatile("" ::: "memory");                                  \
-                    LSM_RING_ADD4(cin[q], wv[p][0])                                             \
-                }                                                                               \
-        } else {                                                                                \
-            _Pragma("unroll") for (int q = 0; q < QL; ++q) LSM_RING_ADD4(cin[q], wv[p][q])      \
-        }                                                                                       \
-        __builtin_amdgcn_sched_barrier(0);                                                      \
-    }
-            // software pipeline: P rows of loads in flight; the LDS hand-off of row m+1 is issued before the
-            // adds of row m, so its round trip hides behind them
+            // software pipeline: P rows of loads in flight; the accumulator reads of row m+1 are issued right
+            // after the writes of row m and their round trip hides behind the scalar work that launches row m+P
 #pragma unroll
-            for (int p = 0; p < P; ++p) LSM_RING_LOAD(p, p)
-            LSM_RING_PARK(0, 0)
+            for (int p = 0; p < P; ++p) {
+                LSM_RING_LOADW(p, p)
+                LSM_RING_LOADL(p, p)
+            }
+            LSM_RING_READ(0)
             for (int m = 0; m < n; m += P) {
 #pragma unroll
                 for (int p = 0; p < P; ++p) {
-                    LSM_RING_PARK((p + 1) % P, (p + 1) & 1)
-                    LSM_RING_ADD(p, p & 1)
-                    LSM_RING_LOAD(p, m + p + P)
+                    LSM_RING_APPLY(p)
+                    LSM_RING_READ((p + 1) % P)
+                    LSM_RING_LOADW(p, m + p + P)
+                    LSM_RING_LOADL(p, m + p + P)
                 }
             }
-#undef LSM_RING_LOAD
-#undef LSM_RING_PARK
-#undef LSM_RING_ADD
+#undef LSM_RING_LOADW
+#undef LSM_RING_LOADL
+#undef LSM_RING_READ
+#undef LSM_RING_APPLY
         }
         input_drive(t);
         wave_lds_fence();
@@ -422,10 +426,13 @@ __global__ __launch_bounds__(WPC * 64) void lif_ring_kernel(const RingArgs a)
 #pragma unroll
         for (int q = 0; q < QL; ++q) {
             const int gq = LSM_RING_GQ(q);
-            const ring_u4 nin = *reinterpret_cast<const ring_u4 *>(myscr + 4 * q);
-            *reinterpret_cast<ring_u4 *>(myscr + 4 * q) = (ring_u4){0u, 0u, 0u, 0u};
-            const uint32_t nn[4] = {nin.x, nin.y, nin.z, nin.w};
-            float ci[4] = {cin[q].x, cin[q].y, cin[q].z, cin[q].w};
+            // my four recurrent sums and input counts of this quad; both arrays are cleared for the next step
+            const ring_f4 cq = *reinterpret_cast<const ring_f4 *>(smem + acc_b + (uint32_t)gq * 1024u);
+            *reinterpret_cast<ring_f4 *>(smem + acc_b + (uint32_t)gq * 1024u) = (ring_f4){0.0f, 0.0f, 0.0f, 0.0f};
+            const ring_u2 nin = *reinterpret_cast<const ring_u2 *>(smem + cnt_b + (uint32_t)gq * 512u);
+            *reinterpret_cast<ring_u2 *>(smem + cnt_b + (uint32_t)gq * 512u) = (ring_u2){0u, 0u};
+            const uint32_t nn[4] = {nin.x & 0xFFFFu, nin.x >> 16, nin.y & 0xFFFFu, nin.y >> 16};
+            float ci[4] = {cq.x, cq.y, cq.z, cq.w};
             unsigned long long bq[4];
 #pragma unroll
             for (int h = 0; h < 4; ++h) {

@@ -50,10 +50,10 @@ struct RingVariant {        // per waves-per-clip layout of the ring-row kernel 
     int wpc = 0, ql = 0, einw = 0;
     bool strided = false;            // quad ownership: wave w owns quads w, w+wpc, ... (else w*ql .. w*ql+ql-1)
     uint32_t *rem_ptr = nullptr;     // (N*wpc + 1) first list entry of (row, wave)
-    uint2 *rem = nullptr;            // synapses outside the ring window: {LDS byte offset, weight bits}
+    uint2 *rem = nullptr;            // synapses outside the ring window: {LDS byte offset of the accumulator, weight bits}
     float *leak = nullptr;
     int *oslot = nullptr;
-    uint32_t *in_ent = nullptr;      // (wpc, einw) (channel << 16) | scratch word index
+    uint32_t *in_ent = nullptr;      // (wpc, einw) (channel << 16) | target neuron
 };
 
 }  // namespace
@@ -326,7 +326,7 @@ int lsm_reservoir_create(lsm_reservoir **out, int num_neurons, int n_channels,
                             uint32_t bits;
                             std::memcpy(&bits, &csc_w[e], 4);
                             rem[fill[(size_t)j * wpc + wave_of(i)]++] =
-                                make_uint2((uint32_t)lsm_lif::ring_scr_word(i, ql, wpc, strided) * 4u, bits);
+                                make_uint2((uint32_t)lsm_lif::ring_acc_word(i) * 4u, bits);
                         }
                     std::vector<float> lk(npad, 0.0f);
                     std::vector<int> os(npad, -1);
@@ -336,8 +336,7 @@ int lsm_reservoir_create(lsm_reservoir **out, int num_neurons, int n_channels,
                     for (int c = 0; c < C; ++c)
                         for (int d = 0; d < in_fanout; ++d) {
                             const int tgt = in_tgt[(size_t)c * in_fanout + d];
-                            per[wave_of(tgt)].push_back(((uint32_t)c << 16) |
-                                                        (uint32_t)lsm_lif::ring_scr_word(tgt, ql, wpc, strided));
+                            per[wave_of(tgt)].push_back(((uint32_t)c << 16) | (uint32_t)tgt);
                         }
                     size_t mx = 1;
                     for (auto &pp : per) mx = std::max(mx, pp.size());
@@ -412,7 +411,9 @@ static size_t ring_lds_bytes(const lsm_reservoir *h, const RingVariant &v, int T
 {
     const size_t npad = (size_t)v.ql * 256 * v.wpc;
     const size_t cw = (size_t)(h->C + 31) / 32;
-    return ((size_t)lsm_lif::RING_DUMP_WORDS + (size_t)v.wpc * 64 * lsm_lif::ring_stride(4 * v.ql)) * 4 +
+    // float32 accumulators + 16-bit input counts (each behind 64 dump words), two step lists, quad counts,
+    // feature accumulators, the clip's input bits
+    return ((size_t)2 * lsm_lif::RING_DUMP_WORDS + npad + npad / 2) * 4 +
            2 * npad * 2 + 512 + (size_t)h->n_out * 16 + (size_t)T * cw * 4;
 }
 

@@ -105,19 +105,19 @@ def test_window_plus_list_reproduce_every_row(n, k, layouts):
                 assert np.all(owners < wpc) and np.bincount(owners, minlength=wpc).max() <= 64
 
 
-def test_scratch_word_layout_is_conflict_free():
-    """ring_scr_word: every neuron of a layout has its own LDS word, beyond the 64 dump words, and the 16-byte
-    reads of any 16 lanes that differ mod 16 fall on 16 distinct 4-bank groups of the 64 banks."""
-    for ql in (1, 2, 4):
-        sl = 4 * ql
-        stride = 4 if sl == 4 else sl + 4
-        for wpc in (2, 4, 8):
-            i = np.arange(wpc * ql * 256)
-            g = i >> 8
-            for w, slot in ((g // ql, g % ql), (g % wpc, g // wpc)):          # contiguous, strided ownership
-                word = 64 + (w * 64 + ((i & 255) >> 2)) * stride + slot * 4 + (i & 3)
-                assert len(np.unique(word)) == len(word) and word.min() >= 64
-                assert word.max() < 64 + wpc * 64 * stride <= 65535
-        lanes = np.arange(16)
-        groups = ((lanes * stride) % 64) // 4
-        assert len(np.unique(groups)) == 16
+def test_accumulator_layout():
+    """ring_acc_word / ring_cnt_word (csrc/lif_ring.h): every neuron has its own float32 accumulator word behind the
+    64 dump words, a lane's four neurons form one aligned 16-byte group and a quad is 1 KB (so the 16-byte accesses
+    of a wave are 64 consecutive groups: conflict-free); the input counts are 16 bits per neuron, two per word,
+    and a lane's four counts are one aligned 8-byte group.  List entries carry acc byte offsets < 64 KB."""
+    for npad in (512, 1024, 4096, 8192):
+        i = np.arange(npad)
+        acc = 64 + i
+        assert len(np.unique(acc)) == npad and acc.min() >= 64 and acc.max() * 4 < 65536
+        lane_groups = acc.reshape(-1, 4)
+        assert np.all(lane_groups[:, 0] % 4 == 0) and np.all(np.diff(lane_groups, axis=1) == 1)
+        assert np.all(acc.reshape(-1, 256)[:, 0] * 4 == 256 + np.arange(npad // 256) * 1024)
+        cnt_word, cnt_half = 64 + (i >> 1), i & 1
+        assert len(np.unique(cnt_word * 2 + cnt_half)) == npad
+        per_lane = (cnt_word * 2 + cnt_half).reshape(-1, 4)
+        assert np.all(per_lane[:, 0] % 4 == 0) and np.all(np.diff(per_lane, axis=1) == 1)
