@@ -7,7 +7,7 @@ LIF reservoir -> features, all on the GPU, and consecutive steps are issued on r
 work of a step is ordered on its own stream, the float64 filterbank of step s+1 runs beside the
 latency-bound reservoir kernel of step s and refills the CUs that clips finishing early leave idle.
 Every step still does all its work; per-step latency grows, throughput rises (measured at 128 filters /
-1000 neurons / 256 clips: 130 k clips/s on one stream, 350 k on six).
+1000 neurons / 256 clips: 132 k clips/s on one stream, 356 k on six).
 
 `HotPath` owns what used to live in bench.py: the stream rotation, the layout hint for the reservoir
 kernel (a launch that shares the chip with other kernels prefers fewer, fatter waves than a lone one:
