@@ -45,25 +45,11 @@
 
 namespace lsm_lif {
 
-// a += b on four floats.  LSM_RING_SCALAR_ADD: four v_add_f32 instead of two v_pk_add_f32 (experiment switch;
-// measured equal: the kernel is bound by the row gathers, not by vector issue)
-#if defined(LSM_RING_SCALAR_ADD)
-#define LSM_RING_ADD4(a, b)                                                          \
-    {                                                                                \
-        float _x = a.x, _y = a.y, _z = a.z, _w = a.w;                                \
-        asm volatile("v_add_f32 %0, %0, %1" : "+v"(_x) : "v"(b.x));                  \
-        asm volatile("v_add_f32 %0, %0, %1" : "+v"(_y) : "v"(b.y));                  \
-        asm volatile("v_add_f32 %0, %0, %1" : "+v"(_z) : "v"(b.z));                  \
-        asm volatile("v_add_f32 %0, %0, %1" : "+v"(_w) : "v"(b.w));                  \
-        a = (ring_f4){_x, _y, _z, _w};                                               \
-    }
-#else
-#define LSM_RING_ADD4(a, b) a = a + b;
-#endif
+#define LSM_RING_ADD4(a, b) a = a + b;      // four floats: two v_pk_add_f32 (four v_add_f32 measured equal)
 
 #ifndef LSM_RING_ABLATE
-#define LSM_RING_ABLATE 0   // diagnostic builds only (1, 2, 8 give WRONG results): 1 = no window loads, 2 = no LDS
-#endif                      // hand-off, 8 = no list loads
+#define LSM_RING_ABLATE 0   // diagnostic builds only (1, 2, 8 give WRONG results): 1 = no window loads, 2 = no
+#endif                      // accumulator read-modify-write, 8 = no list loads
 
 struct RingArgs {
     int N, C, T, B;

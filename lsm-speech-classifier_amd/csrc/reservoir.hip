@@ -258,7 +258,11 @@ int lsm_reservoir_create(lsm_reservoir **out, int num_neurons, int n_channels,
                 q = q < 0 ? q + N : (q >= N ? q - N : q);
                 inside += q < wd;
             }
-        if (H >= 1 && 2 * wd <= N && NQ >= 2 && nnz > 0 && inside * 10 >= nnz * 6) {
+        // (the ring kernel counts a neuron's active input entries of a step in 16 bits)
+        std::vector<uint32_t> fanin(N, 0u);
+        uint32_t max_fanin = 0;
+        for (size_t e = 0; e < (size_t)C * in_fanout; ++e) max_fanin = std::max(max_fanin, ++fanin[in_tgt[e]]);
+        if (H >= 1 && 2 * wd <= N && NQ >= 2 && nnz > 0 && inside * 10 >= nnz * 6 && max_fanin <= 65535u) {
             // geometry per row: a4 (32-aligned first target of the window: 128 bytes), bytes that exist (up to the window's
             // end along the padded ring of NQ*256 positions, 16-byte granules), quads the window touches
             const int NP = NQ * 256;
