@@ -121,3 +121,43 @@ def test_accumulator_layout():
         assert len(np.unique(cnt_word * 2 + cnt_half)) == npad
         per_lane = (cnt_word * 2 + cnt_half).reshape(-1, 4)
         assert np.all(per_lane[:, 0] % 4 == 0) and np.all(np.diff(per_lane, axis=1) == 1)
+
+
+@pytest.mark.parametrize("n,k,wpc", [(1000, 200, 4), (4000, 800, 8)])
+def test_read_modify_write_order_of_a_row(n, k, wpc):
+    """The kernel applies a row to LDS accumulators: read the 1 KB quad under the window load and the words under
+    the list entries, add, write the quad, THEN the list words (csrc/lif_ring.h, APPLY).  Restated here for the
+    strided ownership: a list target often lies in a part of the window quad the window does not cover (the two
+    reads return the same old value; the quad write stores old + 0 there and the list write must come second).
+    Checks that such targets exist in the reservoirs the GPU parity tests use, that the order 'quad, then list'
+    gives W[j -> .] exactly and that the opposite order would not."""
+    p = R.SimulationParams(num_neurons=n, num_output_neurons=n // 2, small_world_graph_k=k, mean_weight=0.01)
+    res = R.build_reservoir(p, 16)
+    H, NQ, a4, nbytes, wsq, band, in_list = ring_tables(n, res.csc_ptr, res.csc_post, res.csc_w)
+    assert NQ % wpc == 0 and wsq <= wpc
+    ql = NQ // wpc
+    npad = NQ * 256
+    overlaps = wrong_if_swapped = 0
+    for jj in list(range(0, n, 41)) + [0, 1, n - 1, H, n - H - 1]:
+        e0, e1 = res.csc_ptr[jj], res.csc_ptr[jj + 1]
+        post, wts = res.csc_post[e0:e1], res.csc_w[e0:e1]
+        lst = in_list[e0:e1]
+        window = fetch_row(jj, wpc, ql, n, NQ, a4, nbytes, band, strided=True)      # zeros where nothing was fetched
+        q0 = int(a4[jj]) >> 8
+        acc = np.arange(npad, dtype=np.float32) * 0.5 + 1.0                         # some old sums
+        want = acc.copy()
+        want[post] += wts
+        got, swapped = acc.copy(), acc.copy()
+        for w in range(wpc):
+            gh = (q0 + (w - q0) % wpc) % NQ                                         # the quad wave w reads and writes
+            quad = slice(gh * 256, gh * 256 + 256)
+            mine = lst & ((post >> 8) % wpc == w)                                   # list entries wave w owns
+            old_quad, old_words = acc[quad].copy(), acc[post[mine]].copy()          # both reads precede both writes
+            overlaps += int(np.sum((post[mine] >> 8) == gh))
+            got[quad] = old_quad + window[quad]
+            got[post[mine]] = old_words + wts[mine]
+            swapped[post[mine]] = old_words + wts[mine]
+            swapped[quad] = old_quad + window[quad]
+        np.testing.assert_array_equal(got[:n], want[:n])
+        wrong_if_swapped += int(np.any(swapped[:n] != want[:n]))
+    assert overlaps > 0 and wrong_if_swapped > 0
