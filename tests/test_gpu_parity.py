@@ -73,6 +73,31 @@ def test_gammatone_partial_workgroups(torch_cuda, oracle_c, n_filters, n_clips):
         np.testing.assert_array_equal(spec[b], oracle_c.gammatone_spec(audio[b], coefs, 400, 160, 98))
 
 
+def test_gammatone_special_sample_values(torch_cuda, oracle_c):
+    """Exact zeros of both signs, float32 denormals (smallest, largest, in between), the smallest and largest
+    normal magnitudes and ordinary values as audio samples must give the oracle's bits (added with an experiment
+    that converted the wave-uniform sample to float64 with scalar integer instructions -- bit-exact, but 1.32 ->
+    2.25 ms per launch, DESIGN.md section 9 -- and kept: padded clips are full of exact zeros)."""
+    from lsm_speech_classifier_amd import frontend
+    from oracle import ref_numpy as O
+    rs = np.random.RandomState(321)
+    special = np.array([0.0, -0.0, 1e-45, -1e-45, 1.1754942e-38, -1.1754942e-38, 3e-42, 7e-40, 1.17549435e-38,
+                        -1.17549435e-38, 3.0e38, -3.0e38, 1.0, -1.0, 0.5, 1.5, 0.1, 123456.789, 2.0 ** -126,
+                        2.0 ** -127, 2.0 ** -149, 2.0 ** 127], dtype=np.float32)
+    audio = (rs.randn(3, 16000) * 0.1).astype(np.float32)
+    audio[0, rs.randint(0, 16000, size=4000)] = special[rs.randint(0, len(special), size=4000)]
+    audio[1, :] = special[rs.randint(0, 12, size=16000)]                 # zeros and denormals only
+    audio[2, 2000:9000] = 0.0                                            # a padded clip
+    bits = audio.view(np.uint32)
+    assert ((bits >> 23) & 0xFF == 0).sum() > 1000                       # zeros and denormals are really there
+    fe = frontend.SpikeFrontEnd(64, "gammatone")
+    coefs = O.gammatone_coefs(16000, 64, 50)
+    _, spec = fe.spectrogram_db(audio, want_spec=True)
+    spec = spec.cpu().numpy()
+    for b in range(3):
+        np.testing.assert_array_equal(spec[b], oracle_c.gammatone_spec(audio[b], coefs, 400, 160, 98))
+
+
 def test_gammatone_large_launch_equals_small_launches(torch_cuda):
     """More workgroups than CUs (no CU-exclusive LDS reservation) must give the same bits as the small
     launches that carry the reservation: 600 clips tiled from 5 distinct ones."""
