@@ -75,6 +75,24 @@ def test_bench_spawns_two_ranks_on_a_shared_gpu():
     assert abs(d["value"] - 2 * 64 / (d["ms_per_step"] * 1e-3)) / d["value"] < 1e-3
 
 
+def test_bench_rccl_code_path_with_one_rank():
+    """The calls the 8-GPU run makes -- process group over RCCL (backend "nccl" on ROCm), broadcast of w_critico,
+    all_gather_into_tensor of the feature rows on its own stream, barrier + max-over-ranks timing -- executed for
+    real on this box's one GPU (LSM_BENCH_FORCE_DIST=1: world size 1)."""
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+               LSM_BENCH_FORCE_DIST="1")
+    env.pop("LSM_BENCH_BACKEND", None)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "6", "--warmup", "2",
+                        "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-3000:]
+    d = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1])
+    assert d["n_gpus"] == 1 and d["value"] > 1e4 and d["steps"] == 6
+
+
 @pytest.mark.parametrize("world,n", [(2, 9), (3, 2)])          # uneven shards; 3 ranks for 2 clips: an empty shard
 def test_extract_all_features_two_ranks_real_reservoir(tmp_path, world, n):
     """extract_all_features under a launcher with the REAL reservoir: the ranks share cuda:0, the
