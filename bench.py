@@ -32,6 +32,9 @@ if ROOT not in sys.path:
 
 CONFIGS = {
     # name: (n_filters, filterbank, N, k, N_out, batch per GPU, audio kind)
+    "cfg1": dict(n_filters=40, filterbank="mel", N=500, k=100, n_out=200, batch=200,
+                 audio="speech_like", desc="BASELINE configs[0], the reference's CPU-runnable case: 40 mel "
+                 "filters, 500-neuron reservoir, batches of 200 clips"),
     "cfg2": dict(n_filters=128, filterbank="gammatone", N=1000, k=200, n_out=400, batch=256,
                  audio="speech_like", desc="12-class-like synthetic speech, 128 gammatone filters, "
                  "1000-neuron reservoir, batch=256 per GPU"),
@@ -130,10 +133,14 @@ def cpu_baseline(cfg, audio, res, seconds_budget=24.0):
     from lsm_speech_classifier_amd import frontend
     from oracle import cport, ref_numpy
     cport.build()
-    coefs = ref_numpy.gammatone_coefs(16000, cfg["n_filters"], 50)
     thr, gap = frontend.SPIKE_THRESHOLDS, frontend.HYSTERESIS_GAP
+    mel = cfg["filterbank"] == "mel"
+    coefs = None if mel else ref_numpy.gammatone_coefs(16000, cfg["n_filters"], 50)
 
     def front(a):
+        if mel:      # NumPy restatement of the librosa defaults (oracle/ref_numpy.py), float32 like the reference
+            return ref_numpy.encode_hysteresis(ref_numpy.normalise_resize(ref_numpy.mel_db(a, cfg["n_filters"])),
+                                               thr, gap)
         return cport.encode_hysteresis(cport.normalise_resize(cport.gammatone_db(
             cport.gammatone_spec(a, coefs, 400, 160, 98))), thr, gap)
 
@@ -149,6 +156,10 @@ def cpu_baseline(cfg, audio, res, seconds_budget=24.0):
     for a in audio[:n]:
         one(a)
     t_serial = time.perf_counter() - t0
+    if mel:
+        return {"value": round(n / t_serial, 3), "unit": "clips/s", "cores": 1, "kind": "port",
+                "sample": f"{n} clips of the same workload, NumPy mel front end + C gather-form LIF, one clip at "
+                          f"a time on one core"}
     cores = os.cpu_count() or 1
     # all cores: enough clips to give every core work for about a third of the budget
     n_all = int(max(n, min(len(audio), cores * max(1, round(seconds_budget / 3 / max(per_clip, 1e-4))))))
@@ -319,7 +330,9 @@ def run_rank(args):
                       else f"clips/sec ({args.config})",
             "value": round(value, 2), "unit": "clips/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(ms_step, 4), "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f32 (reservoir) / f64 (gammatone)",
+            "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32 (reservoir) / f64 (gammatone)" if cfg["filterbank"] == "gammatone"
+                     else "f32 (reservoir, mel projection) / f64 (FFT)",
             "data": "synthetic",
             "config": {"workload": f"{args.config}: {cfg['desc']}", "stage": args.stage,
                        "clips_per_gpu": B, "n_filters": cfg["n_filters"], "num_neurons": cfg["N"],
