@@ -142,7 +142,10 @@ int lsm_reservoir_kernel_in_use(const lsm_reservoir *h);
  *                    whole reservoir} -- what run_network_diagnostics (:119-133) derives from lsm.spike_matrix
  *                    (participation, dead neurons, mean spikes per neuron), accumulated inside the kernel
  *   waves_per_clip   0 = choose for a lone launch of this batch size; -1 = choose for a launch that shares
- *                    the GPU with other kernels of an overlapped pipeline; else 1, 2, 4, 8 or 16 */
+ *                    the GPU with other kernels of an overlapped pipeline; else 1, 2, 4, 8 or 16
+ * Fails (LSM_ERR, "no ... layout") when no layout's per-clip LDS image fits a CU's 160 KB: roughly
+ * 10*N + 16*n_out + n_steps*ceil(n_channels/32)*4 bytes for ring rows (e.g. N = 8000 with more than ~4500 output
+ * neurons); every BASELINE configuration fits (N = 8000, n_out = 3200, 256 channels: 145 KB). */
 int lsm_reservoir_run(const lsm_reservoir *h, const uint8_t *spikes_u8, int n_clips, int n_steps,
                       const int32_t *key_ids, int n_keys, float *features_out,
                       uint8_t *spike_matrix_out, float *v_trace_out, int32_t *stats_out,
