@@ -3,7 +3,9 @@ librosa==0.11.0 and snn_reservoir_py==2.0.0 are absent: SURVEY.md §8c).  They c
 make sure they do not merely agree with themselves:
 
 * the gammatone coefficient table is checked against its DEFINITION with scipy.signal.freqz (unit gain at
-  the centre frequency, ERB spacing, ERB-proportional bandwidth), not against the second copy of the table;
+  the centre frequency, ERB spacing, ERB-proportional bandwidth), not against the second copy of the table,
+  and against scipy.signal.gammatone -- SciPy's own implementation of the same published filter -- coefficient by
+  coefficient;
 * the STFT and the mel filterbank against scipy.signal / torch.stft and closed-form triangle areas;
 * the hand-rolled Watts-Strogatz wiring against networkx.watts_strogatz_graph statistics over 20 seeds;
 * (GPU, tests/test_gpu_parity.py::test_oracle_on_a_reservoir_it_did_not_build) the LIF oracle and the
@@ -68,6 +70,50 @@ def test_gammatone_bandwidth_follows_the_erb():
         erb = cfs[ch] / O.EAR_Q + O.MIN_BW
         want = 2 * np.sqrt(2 ** 0.25 - 1) * 1.019 * erb
         assert abs(bw / want - 1) < 0.03, (ch, bw, want)
+
+
+@pytest.mark.parametrize("channels", [40, 128, 256])
+def test_gammatone_table_equals_scipy_signal_gammatone(channels):
+    """An independent implementation of the same published filter: scipy.signal.gammatone(cf, 'iir', fs) (SciPy's own
+    code after Slaney 1993: 4th order, bandwidth 1.019 ERB, unit gain at cf) returns the 8th-order transfer function
+    as two polynomials.  The four sections of every table row, multiplied out and divided by `gain`, must be those
+    polynomials -- filter design AND gain normalisation, for the oracle's table and the product's."""
+    from lsm_speech_classifier_amd import frontend
+    cfs = O.erb_centre_freqs(FS, channels, 50)[::-1]
+    for name, tab in (("oracle", O.gammatone_coefs(FS, channels, 50)),
+                      ("product", frontend.gammatone_filter_table(FS, channels, 50))):
+        for ch in range(channels):
+            A0, A11, A12, A13, A14, A2, B0, B1, B2, gain = tab[ch]
+            assert A2 == 0.0 and B0 == 1.0
+            num, den = np.array([1.0]), np.array([1.0])
+            for a1 in (A11, A12, A13, A14):
+                num = np.convolve(num, [A0, a1])
+                den = np.convolve(den, [B0, B1, B2])
+            b, a = signal.gammatone(cfs[ch], "iir", fs=FS)
+            assert len(b) == 5 and len(a) == 9
+            np.testing.assert_allclose(num / gain, b, rtol=0, atol=2e-11 * np.abs(b).max(), err_msg=f"{name} ch {ch}")
+            np.testing.assert_allclose(den, a, rtol=0, atol=1e-13 * np.abs(a).max(), err_msg=f"{name} ch {ch}")
+
+
+def test_gammatone_filterbank_output_against_scipy_signal_gammatone():
+    """Time domain: erb_filterbank (the oracle's four-section cascade, / gain) against scipy.signal.lfilter over
+    SciPy's own 8th-order polynomials of the same filter.  The direct 8th-order form loses precision as the poles
+    approach z = 1 (1e-2 at 50 Hz, 5e-5 at 154 Hz -- the reason the cascade is the form everybody evaluates), so the
+    bound tightens with the centre frequency."""
+    rng = np.random.default_rng(11)
+    x = rng.standard_normal(4000)
+    cfs = O.erb_centre_freqs(FS, 32, 50)[::-1]
+    y = O.erb_filterbank(x, O.gammatone_coefs(FS, 32, 50))
+    checked = 0
+    for ch in range(32):
+        if cfs[ch] < 450:
+            continue
+        b, a = signal.gammatone(cfs[ch], "iir", fs=FS)
+        ref = signal.lfilter(b, a, x)
+        tol = 2e-6 if cfs[ch] < 1000 else 1e-8
+        assert np.max(np.abs(y[ch] - ref)) <= tol * np.max(np.abs(ref)), (ch, cfs[ch])
+        checked += 1
+    assert checked >= 20
 
 
 def test_gammatone_filterbank_equals_an_independent_sos_cascade():
