@@ -6,7 +6,8 @@ make sure they do not merely agree with themselves:
   the centre frequency, ERB spacing, ERB-proportional bandwidth), not against the second copy of the table,
   and against scipy.signal.gammatone -- SciPy's own implementation of the same published filter -- coefficient by
   coefficient;
-* the STFT and the mel filterbank against scipy.signal / torch.stft and closed-form triangle areas;
+* the STFT and the mel filterbank against scipy.signal / torch.stft and closed-form triangle areas, and the whole
+  mel front end against transformers.audio_utils (an independent implementation modelled on librosa);
 * the hand-rolled Watts-Strogatz wiring against networkx.watts_strogatz_graph statistics over 20 seeds;
 * (GPU, tests/test_gpu_parity.py::test_oracle_on_a_reservoir_it_did_not_build) the LIF oracle and the
   kernels on a random CSR that reservoir.build_reservoir never produced.
@@ -151,6 +152,32 @@ def test_stft_power_against_scipy_and_torch():
                    pad_mode="constant", return_complex=True)
     ref_t = (T.abs() ** 2).numpy()
     np.testing.assert_allclose(S, ref_t, rtol=2e-4, atol=1e-6 * ref_t.max())
+
+
+def test_mel_front_end_against_transformers_audio_utils():
+    """An independent implementation modelled on librosa: Hugging Face's transformers.audio_utils (mel_filter_bank with
+    Slaney scale and normalisation, spectrogram with a periodic hann window, centred frames, zero padding, power 2,
+    power_to_db with ref = max, amin 1e-10, 80 dB range).  The oracle's mel filterbank, mel power spectrogram and dB
+    spectrogram (create_dataset.py:43-48 through librosa 0.11's defaults) must be its numbers."""
+    au = pytest.importorskip("transformers.audio_utils")
+    for n_mels in (13, 40, 128):
+        fb = au.mel_filter_bank(num_frequency_bins=O.MEL_N_FFT // 2 + 1, num_mel_filters=n_mels, min_frequency=0.0,
+                                max_frequency=FS / 2, sampling_rate=FS, norm="slaney", mel_scale="slaney")
+        mine = O.mel_filterbank(FS, O.MEL_N_FFT, n_mels)
+        assert np.max(np.abs(fb.T - mine)) <= 2e-7 * np.max(np.abs(mine)), n_mels
+    rng = np.random.default_rng(0)
+    t = np.arange(FS) / FS
+    for k, x in enumerate([(rng.standard_normal(FS) * 0.1).astype(np.float32),
+                           (0.5 * np.sin(2 * np.pi * (200 + 900 * t) * t) * np.hanning(FS)).astype(np.float32)]):
+        win = au.window_function(O.MEL_N_FFT, "hann", periodic=True)
+        fb = au.mel_filter_bank(O.MEL_N_FFT // 2 + 1, 40, 0.0, FS / 2, FS, norm="slaney", mel_scale="slaney")
+        ref = au.spectrogram(x, win, frame_length=O.MEL_N_FFT, hop_length=160, fft_length=O.MEL_N_FFT, power=2.0,
+                             center=True, pad_mode="constant", mel_filters=fb)
+        mine = O.mel_power(x, 40, FS, 160)
+        assert ref.shape == mine.shape == (40, 101)
+        assert np.max(np.abs(ref - mine)) <= 2e-6 * np.max(np.abs(mine)), k
+        ref_db = au.power_to_db(ref, reference=float(ref.max()), min_value=1e-10, db_range=80.0)
+        assert np.max(np.abs(ref_db - O.power_to_db(mine))) <= 5e-5, k
 
 
 @pytest.mark.parametrize("n_mels", [40, 128])
