@@ -47,6 +47,20 @@ CONFIGS = {
 FEATURE_SET = ['spike_counts', 'spike_variances', 'mean_spike_times', 'mean_isi', 'isi_variances']
 MULTIPLIER = 0.6
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8 TB/s spec
+
+
+def gather_ceiling_gbs(table_bytes):
+    """What the memory system serves a random-row gather from a table of this size, chip-wide (MI355X_MICROARCH.md,
+    'Indexed rows: gather into LDS', measured): rows every workgroup shares inside each XCD's 4 MiB L2 16.8-18.8 TB/s;
+    a 38 MB table (Infinity Cache) 8.6 TB/s; 151 MB 7.4-7.9 TB/s; beyond the 256 MiB Infinity Cache (HBM) 6.0-6.1 TB/s.
+    The lower figure of each range is used."""
+    if table_bytes <= 4.5 * 2 ** 20:
+        return 16800.0, "table within one XCD's L2 (4 MiB): 16.8 TB/s"
+    if table_bytes <= 40e6:
+        return 8600.0, "table <= 38 MB, served by the Infinity Cache: 8.6 TB/s"
+    if table_bytes <= 256 * 2 ** 20:
+        return 7400.0, "table <= 256 MiB, served by the Infinity Cache: 7.4 TB/s (151 MB measurement)"
+    return 6000.0, "table beyond the Infinity Cache, served by HBM: 6.0 TB/s"
 F64_UNFUSED_PEAK_TOPS = 39.3   # one float64 operation per lane and instruction, all 1024 SIMDs (exp/ubench_f64.hip)
 
 
@@ -67,6 +81,10 @@ def parse_args(argv=None):
                          "rate; never the contract's `value`, which is quoted on HBM-resident inputs)")
     ap.add_argument("--streams", type=int, default=0,
                     help="HIP streams the steps rotate over (0 = the pipeline's default; 1 = serial)")
+    ap.add_argument("--exchange", default="once", choices=["once", "per-step"],
+                    help="N > 1: 'once' = every rank keeps its steps' feature rows and ONE all-gather follows the "
+                         "last step, inside the timed region (what the product does: one gather per split, "
+                         "extract_lsm_features.py); 'per-step' = an all-gather behind every step's reservoir kernel")
     return ap.parse_args(argv)
 
 
@@ -74,27 +92,54 @@ def parse_args(argv=None):
 def spawn_ranks(n: int) -> int:
     """`python bench.py --gpus N` without torchrun: start N fresh rank processes of this script (the parent
     has not touched the GPU and never does), one per GPU, and return the worst exit status.  Rank 0 prints
-    the JSON line on the inherited stdout."""
-    with socket.socket() as s:                      # a free rendezvous port
-        s.bind(("127.0.0.1", 0))
-        port = s.getsockname()[1]
+    the JSON line on the inherited stdout.  The children are POLLED: when one exits non-zero while others still
+    sit in the rendezvous or a collective, the rest are terminated (then killed) and that status is returned at
+    once instead of after the process-group timeout."""
+    sock = socket.socket()                          # a free rendezvous port, held until the children are started
+    sock.bind(("127.0.0.1", 0))
+    port = sock.getsockname()[1]
     procs = []
-    for r in range(n):
-        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n),
-                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
-    rc = 0
-    for p in procs:
-        rc = max(rc, abs(p.wait()))
+    try:
+        for r in range(n):
+            env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n),
+                       MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+            procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+        sock.close()          # rank 0 binds it seconds later (interpreter start + import torch); nobody else has the number
+        rc = 0
+        while True:
+            codes = [p.poll() for p in procs]
+            bad = [abs(c) for c in codes if c not in (None, 0)]
+            if bad:
+                rc = max(bad)
+                break
+            if all(c == 0 for c in codes):
+                return 0
+            time.sleep(0.05)
+    finally:
+        sock.close()
+        live = [p for p in procs if p.poll() is None]
+        if live:                                    # only on the failure path: these are this call's own children
+            for p in live:
+                p.terminate()
+            deadline = time.time() + 5.0
+            for p in live:
+                try:
+                    p.wait(timeout=max(0.1, deadline - time.time()))
+                except subprocess.TimeoutExpired:
+                    p.kill()
+                    p.wait()
     return rc
 
 
 def spawn_check():
     """LSM_BENCH_SPAWN_ONLY=1: the launcher path without a GPU -- every rank joins a gloo group, the ranks
     are summed, rank 0 reports (tests/test_bench_spawn.py)."""
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    die = os.environ.get("LSM_BENCH_SPAWN_DIE")     # "<rank>:<code>": that rank exits before the rendezvous
+    if die and int(die.split(":")[0]) == rank:
+        sys.exit(int(die.split(":")[1]))
     import torch
     import torch.distributed as dist
-    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
     dist.init_process_group("gloo")
     t = torch.tensor([float(rank)])
     dist.all_reduce(t)
@@ -240,30 +285,26 @@ def run_rank(args):
                  time_reservoir=True)
     lay = net.layout(B, fe.n_steps, hp.waves_per_clip)
     audio_pinned = torch.from_numpy(audio_np).pin_memory() if args.from_host else None
-    # one gather buffer per stream of the rotation: overlapping steps never share an output
+    per_step = use_dist and args.exchange == "per-step"
+    once = use_dist and not per_step
+    stage_in = rasters0 if args.stage == "reservoir" else (audio_pinned if args.from_host else audio)
+    # per-step exchange: one gather buffer per stream of the rotation (overlapping steps never share an output);
+    # one exchange: every step writes its rows into its own slice of a per-rank block, gathered once at the end
     gather_bufs = ([torch.empty((world * B, n_feat), dtype=torch.float32, device=dev)
-                    for _ in range(hp.n_streams)] if use_dist else None)
+                    for _ in range(hp.n_streams)] if per_step and args.stage != "frontend" else None)
+    n_slots = max(args.steps, args.warmup, 1)
+    local_rows = (torch.empty((n_slots, B, n_feat), dtype=torch.float32, device=dev)
+                  if once and args.stage != "frontend" else None)
+    gathered = (torch.empty((world * args.steps * B, n_feat), dtype=torch.float32, device=dev)
+                if local_rows is not None else None)
 
-    def step():
-        """One pass of the hot path over the batch on the next stream of the rotation."""
+    def step(i):
+        """One pass of the hot path over the batch on the next stream of the rotation (HotPath.submit, also for
+        the --stage variants)."""
         slot = hp._step % hp.n_streams
-        if args.stage == "frontend":
-            st = hp.streams[slot]
-            hp._step += 1
-            with torch.cuda.stream(st) if st is not None else torch.cuda.stream(torch.cuda.current_stream()):
-                return fe.encode(audio)
-        if args.stage == "reservoir":
-            st = hp.streams[slot]
-            hp._step += 1
-            with torch.cuda.stream(st) if st is not None else torch.cuda.stream(torch.cuda.current_stream()):
-                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                e0.record()
-                feats, _, _ = net.run_batch(rasters0, FEATURE_SET, waves_per_clip=hp.waves_per_clip)
-                e1.record()
-                hp.reservoir_events.append((e0, e1))
-                return feats
-        feats, st = hp.submit(audio_pinned if args.from_host else audio)
-        if use_dist:
+        out_rows = local_rows[i] if local_rows is not None else None
+        feats, st = hp.submit(stage_in, out=out_rows, stage=args.stage)
+        if gather_bufs is not None:
             # RCCL's stream is ordered after this step's reservoir kernel and the step's stream after the
             # gather; with >= 12 hardware queues the exchange does not disturb the other steps in flight
             with torch.cuda.stream(st):
@@ -271,22 +312,35 @@ def run_rank(args):
             return gather_bufs[slot]
         return feats
 
+    def exchange_once(n_steps):
+        """What the product does (extract_lsm_features.py: one gather per split): the rows of all `n_steps` steps
+        of this rank travel in ONE all-gather, ordered behind every stream of the rotation without a host wait."""
+        if gathered is None:
+            return None
+        hp.join_to_current()
+        dist.all_gather_into_tensor(gathered[: world * n_steps * B], local_rows[:n_steps].reshape(n_steps * B, n_feat))
+        return gathered
+
     def fence():
         torch.cuda.synchronize()
         if use_dist:
             dist.barrier()
             torch.cuda.synchronize()
 
-    hp.prime(audio_pinned if args.from_host else audio)   # set-up: every stream's allocator pool and first launch
+    hp.prime(stage_in, stage=args.stage)   # set-up: every stream's allocator pool and first launch
     hp.fork_from_current()             # inputs were produced on the default stream
-    for _ in range(args.warmup):
-        out = step()
+    for i in range(args.warmup):
+        out = step(i)
+    if args.warmup and gathered is not None:
+        exchange_once(min(args.warmup, args.steps))   # RCCL's own one-off set-up belongs to the warm-up too
     fence()
     hp.reservoir_events.clear()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        out = step()
+    for i in range(args.steps):
+        out = step(i)
     host_enqueue_ms = (time.perf_counter() - t0) / args.steps * 1e3      # host side of a step (asynchronous)
+    if gathered is not None:
+        out = exchange_once(args.steps)                                  # inside the timed region, before the fence
     fence()
     elapsed = time.perf_counter() - t0
     if use_dist:
@@ -318,9 +372,17 @@ def run_rank(args):
         lone_ms = median_ms(lambda: net.run_batch(rasters0, FEATURE_SET, waves_per_clip=0))
         serial_ms = median_ms(lambda: net.run_batch(rasters0, FEATURE_SET, waves_per_clip=hp.waves_per_clip))
 
-    spikes_per_clip = None
+    spikes_per_clip = spikes_total = None
+    if rank == 0 and args.stage != "frontend":
+        st = torch.empty((B, 2), dtype=torch.int32, device=dev)       # untimed: reservoir spikes of the batch
+        net.run_batch(rasters0, FEATURE_SET, stats_out=st)
+        spikes_total = int(st[:, 1].sum())
     if args.stage != "frontend":
-        spikes_per_clip = float(out[:B].float()[:, :cfg["n_out"]].sum(dim=1).mean())
+        rows = local_rows[args.steps - 1] if local_rows is not None else out[:B]
+        spikes_per_clip = float(rows.float()[:, :cfg["n_out"]].sum(dim=1).mean())
+        if gathered is not None:       # the gathered block holds every rank's rows: this rank's come back unchanged
+            mine = gathered[rank * args.steps * B: (rank + 1) * args.steps * B]
+            assert torch.equal(mine, local_rows[:args.steps].reshape(-1, n_feat)), "all-gather returned other rows"
 
     if rank == 0:
         ms_step = elapsed / args.steps * 1e3
@@ -345,7 +407,10 @@ def run_rank(args):
                        "streams": hp.n_streams, "hw_queues": hp.hw_queues,
                        "pipeline": "pipeline.HotPath: steps rotate over the streams" if hp.n_streams > 1 else "serial",
                        "mean_output_spikes_per_clip": spikes_per_clip,
-                       "sharding": f"clips x{world}, feature all-gather" if world > 1 else "single GPU"},
+                       "sharding": (f"clips x{world}, one feature all-gather after the last step (as the product: one "
+                                    f"gather per split)" if once else
+                                    f"clips x{world}, feature all-gather behind every step") if use_dist and world > 1
+                                   else ("single GPU" if not use_dist else f"1 rank, distributed code path ({args.exchange})")},
         }
         if ev_pairs:
             lif_ms = sum(a.elapsed_time(b) for a, b in ev_pairs) / len(ev_pairs)
@@ -356,12 +421,22 @@ def run_rank(args):
             kname = {"dense": "lif_dense_kernel", "ring": "lif_ring_kernel", "sparse": "lif_kernel"}[net.kernel_in_use()]
             traffic = None
             tfile = os.environ.get("LSM_TRAFFIC_FILE") or os.path.join(ROOT, "profiles", "lif_traffic.json")
+            tkey = f"{args.config}_B{B}_{net.kernel_in_use()}"
             if os.path.exists(tfile):
-                traffic = json.load(open(tfile)).get(f"{args.config}_B{B}_{net.kernel_in_use()}")
+                traffic = json.load(open(tfile)).get(tkey)
+            # NOT measured in this run: the PMC passes are separate rocprofv3 runs whose per-launch result is committed
+            traffic_source = (f"{os.path.relpath(tfile, ROOT)}[{tkey}]: rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE, separate "
+                              f"passes on lone launches, (2*FETCH + WRITE)*1024 per launch -- a committed constant, "
+                              f"not measured in this run" if traffic is not None else
+                              f"none: {os.path.relpath(tfile, ROOT)} has no entry '{tkey}' (no --pmc passes were "
+                              f"collected for this shape)")
+            plan = net.plan(B, fe.n_steps, hp.waves_per_clip)
+            ceiling, ceiling_note = gather_ceiling_gbs(plan["table_bytes"])
+            row_bytes = plan["table_bytes"] / cfg["N"]
             line["roofline"] = {
                 "bound": "hbm", "kernel": kname, "achieved": round(achieved, 2),
                 "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
-                "traffic": traffic, "kernel_ms": round(lif_ms, 4),
+                "traffic": traffic, "traffic_source": traffic_source, "kernel_ms": round(lif_ms, 4),
                 "bytes_per_clip": round(per_clip, 1),
                 "variant": "streamed (C*T + 4*F_feat + T*|W|/B, SURVEY.md 8d); |W| = 8 B x nnz",
                 "traffic_over_algorithmic": None if traffic is None else round(traffic / (per_clip * B), 3),
@@ -378,6 +453,18 @@ def run_rank(args):
                 "idle_gpu_kernel_ms": None if serial_ms is None else round(serial_ms, 4),
                 "idle_gpu_frac": None if serial_ms is None else
                 round(per_clip * B / (serial_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
+                # what an event-driven kernel really asks of the memory system: one weight row per reservoir spike
+                "weight_table_bytes": plan["table_bytes"], "gather_ceiling": ceiling, "gather_ceiling_note": ceiling_note,
+                "row_gather": None if lone_ms is None or spikes_total is None else {
+                    "rows_per_launch": spikes_total, "mean_row_bytes": round(row_bytes, 1),
+                    "gbs_lone_launch": round(spikes_total * row_bytes / (lone_ms * 1e-3) / 1e9, 1),
+                    "frac_of_gather_ceiling": round(spikes_total * row_bytes / (lone_ms * 1e-3) / 1e9 / ceiling, 4),
+                    "note": "reservoir spikes of the batch (stats_out of one untimed launch) x mean bytes of a weight "
+                            "row of the table in use / lone-launch time; served by L2 when the table fits it"},
+                "memory_side_gbs_lone_launch": None if traffic is None or lone_ms is None else
+                round(traffic / (lone_ms * 1e-3) / 1e9, 1),
+                "memory_side_frac": None if traffic is None or lone_ms is None else
+                round(traffic / (lone_ms * 1e-3) / 1e9 / ceiling, 4),
             }
             if gt_ms is not None:
                 # the kernel that takes most of the GPU time is the float64 filterbank, bound by vector-ALU issue:

@@ -80,30 +80,49 @@ def create_pure_redundancy(spike_train: np.ndarray, redundancy_factor: int) -> n
     return np.repeat(spike_train, redundancy_factor, axis=0)
 
 
-def _collect_audio(commands, root: Path, per_class: int):
-    clips, labels = [], []
+def _list_files(commands, root: Path, per_class: int, verbose: bool = True):
+    """The (wav path, label) pairs the reference's loop visits, in its order: classes in list order, the first
+    `per_class` files of each folder in sorted order (create_dataset.py:130-143)."""
+    listing = []
     for label, word in enumerate(commands):
-        print(f"Processing '{word}'...")
+        if verbose:
+            print(f"Processing '{word}'...")
         folder = root / word
         if not folder.is_dir():
-            print(f"  Warning: Directory not found, skipping: {folder}")
+            if verbose:
+                print(f"  Warning: Directory not found, skipping: {folder}")
             continue
         files = sorted(folder.glob("*.wav"))[:per_class]
-        if not files:
+        if not files and verbose:
             print(f"  Warning: No files found for '{word}'")
-            continue
-        for f in files:
-            audio = load_audio_file(f)
-            if audio is not None:
-                clips.append(audio)
-                labels.append(label)
+        listing += [(f, label) for f in files]
+    return listing
+
+
+def _load_listing(listing):
+    clips, labels = [], []
+    for f, label in listing:
+        audio = load_audio_file(f)
+        if audio is not None:
+            clips.append(audio)
+            labels.append(label)
     return clips, labels
+
+
+def _collect_audio(commands, root: Path, per_class: int):
+    return _load_listing(_list_files(commands, root, per_class))
 
 
 def _synthetic_audio(commands, per_class: int):
     from lsm_speech_classifier_amd import synth
     labels = np.repeat(np.arange(len(commands)), per_class)
     return list(synth.class_chirps(labels, seed=1234)), list(labels)
+
+
+def read_commands_file(path) -> list:
+    """One class name per line (blank lines and #-comments skipped)."""
+    with open(path) as fh:
+        return [ln.strip() for ln in fh if ln.strip() and not ln.lstrip().startswith("#")]
 
 
 def collect_audio(commands=None, dataset_root=None, max_per_class: int = MAX_SAMPLES_PER_CLASS,
@@ -129,30 +148,63 @@ def create_dataset(n_filters: int, filterbank: str, commands=None, dataset_root=
     what the reference hard-codes (class list, corpus folder, per-class cap) plus a synthetic
     corpus for machines without Speech Commands.  ``packed=True`` writes the bit-packed schema of
     ``lsm_speech_classifier_amd.spikefile`` (rasters packed on the GPU, 8x fewer bytes off the
-    device and on disk); the default is the reference's uint8 schema."""
+    device and on disk); the default is the reference's uint8 schema.
+
+    Under a launcher (torchrun: RANK / WORLD_SIZE) the clip loop of create_dataset.py:143 shards: rank r reads
+    and encodes the r-th contiguous block of the file listing on its own GPU, the raster blocks are all-gathered
+    in rank order (= the single-process order) and rank 0 writes the file -- the same bytes as one process."""
+    from lsm_speech_classifier_amd import dist as lsm_dist
+    rank, _, world = lsm_dist.init()
     commands = list(COMMANDS if commands is None else commands)
     root = Path(DATASET_ROOT if dataset_root is None else dataset_root)
-    print(f"Creating dataset with filterbank: {filterbank}, filters: {n_filters}")
+    if rank == 0:
+        print(f"Creating dataset with filterbank: {filterbank}, filters: {n_filters}"
+              + (f" ({world} ranks)" if world > 1 else ""))
     if synthetic_per_class > 0:
         clips, labels = _synthetic_audio(commands, synthetic_per_class)
+        lo, hi = lsm_dist.shard_range(len(clips), rank, world)
+        clips, labels = clips[lo:hi], labels[lo:hi]
     else:
-        clips, labels = _collect_audio(commands, root, max_per_class)
-    if not clips:
+        listing = _list_files(commands, root, max_per_class, verbose=rank == 0)
+        lo, hi = lsm_dist.shard_range(len(listing), rank, world)
+        clips, labels = _load_listing(listing[lo:hi])
+    if not clips and world == 1:
         print("\nERROR: No audio files were successfully processed.")
         return
 
-    fe = _frontend().SpikeFrontEnd(n_filters, filterbank, redundancy=REDUNDANCY_FACTOR,
+    import torch
+    dev = lsm_dist.local_device() if world > 1 else None
+    fe = _frontend().SpikeFrontEnd(n_filters, filterbank, device=dev, redundancy=REDUNDANCY_FACTOR,
                                    thresholds=SPIKE_THRESHOLDS, gap=HYSTERESIS_GAP,
                                    time_bins=TIME_BINS, n_samples=int(SAMPLE_RATE * DURATION))
     from lsm_speech_classifier_amd import spikefile
     parts, n_spikes = [], 0
-    for lo in range(0, len(clips), ENCODE_BATCH):
-        batch = np.stack(clips[lo:lo + ENCODE_BATCH])
+    for a in range(0, len(clips), ENCODE_BATCH):
+        batch = np.stack(clips[a:a + ENCODE_BATCH])
         raster = fe.encode(batch)
         n_spikes += int(raster.count_nonzero())
-        parts.append((_frontend().pack_raster(raster) if packed else raster).cpu().numpy())
-    X = np.concatenate(parts).astype(np.uint8, copy=False)
-    y_labels = np.asarray(labels, dtype=np.int32)
+        part = _frontend().pack_raster(raster) if packed else raster
+        parts.append(part if world > 1 else part.cpu().numpy())
+    if world > 1:
+        # one exchange: every rank's rows (device, flattened) and labels, in rank order
+        width = fe.n_channels * ((fe.n_steps + 7) // 8 if packed else fe.n_steps)
+        local = (torch.cat(parts).reshape(len(clips), width) if parts
+                 else torch.empty((0, width), dtype=torch.uint8, device=fe.device))
+        rows = lsm_dist.gather_varrows(local)
+        y_all = lsm_dist.gather_varrows(torch.tensor(labels, dtype=torch.int32, device=fe.device).reshape(-1, 1))
+        tot = lsm_dist.gather_varrows(torch.tensor([[n_spikes]], dtype=torch.int64, device=fe.device))
+        lsm_dist.finish()
+        if rank != 0:
+            return
+        if rows.shape[0] == 0:
+            print("\nERROR: No audio files were successfully processed.")
+            return
+        X = rows.cpu().numpy().reshape(rows.shape[0], fe.n_channels, -1)
+        y_labels = y_all.cpu().numpy().reshape(-1).astype(np.int32)
+        n_spikes = int(tot.sum())
+    else:
+        X = np.concatenate(parts).astype(np.uint8, copy=False)
+        y_labels = np.asarray(labels, dtype=np.int32)
 
     print("\nDataset created successfully.")
     print(f"  Shape: {(len(X), fe.n_channels, fe.n_steps)}" + (" (bit-packed on disk)" if packed else ""))
@@ -164,17 +216,39 @@ def create_dataset(n_filters: int, filterbank: str, commands=None, dataset_root=
     print(f"Saved to '{output_file}'")
 
 
+def add_corpus_flags(ap):
+    """What the reference hard-codes at create_dataset.py:15,108-120 as flags, defaults = the reference's values
+    (shared with main.py, which forwards them)."""
+    ap.add_argument("--commands", type=str, default=None,
+                    help="Comma-separated class list (default: the reference's 12 words).")
+    ap.add_argument("--commands-file", type=str, default=None, help="File with one class name per line.")
+    ap.add_argument("--dataset-root", type=str, default=None,
+                    help=f"Corpus folder with one sub-folder per class (default: {DATASET_ROOT}).")
+    ap.add_argument("--max-per-class", type=int, default=MAX_SAMPLES_PER_CLASS,
+                    help="Per-class cap on the sorted file list.")
+    ap.add_argument("--synthetic-per-class", type=int,
+                    default=int(os.environ.get("LSM_SYNTHETIC_PER_CLASS", "0")),
+                    help="Generate this many synthetic clips per class instead of reading wav files.")
+
+
+def commands_from_args(a):
+    if a.commands_file:
+        return read_commands_file(a.commands_file)
+    if a.commands:
+        return [w.strip() for w in a.commands.split(",") if w.strip()]
+    return None
+
+
 if __name__ == "__main__":
     ap = argparse.ArgumentParser(description="Create a spike train dataset from audio files.")
     ap.add_argument("--n-filters", type=int, default=128, help="Number of filters for the filterbank.")
     ap.add_argument("--filterbank", type=str, default="gammatone", choices=["mel", "gammatone"],
                     help="Type of filterbank to use.")
-    ap.add_argument("--synthetic-per-class", type=int,
-                    default=int(os.environ.get("LSM_SYNTHETIC_PER_CLASS", "0")),
-                    help="Generate this many synthetic clips per class instead of reading wav files.")
+    add_corpus_flags(ap)
     ap.add_argument("--packed", action="store_true",
                     default=os.environ.get("LSM_PACKED_DATASET", "0") == "1",
                     help="Write the bit-packed File 1 schema (8x fewer raster bytes).")
     a = ap.parse_args()
-    create_dataset(n_filters=a.n_filters, filterbank=a.filterbank,
+    create_dataset(n_filters=a.n_filters, filterbank=a.filterbank, commands=commands_from_args(a),
+                   dataset_root=a.dataset_root, max_per_class=a.max_per_class,
                    synthetic_per_class=a.synthetic_per_class, packed=a.packed)

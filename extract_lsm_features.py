@@ -38,6 +38,33 @@ FEATURE_SETS = {
 np.random.seed(42)
 
 
+def reservoir_shape(num_neurons=None, num_output_neurons=None, small_world_k=None):
+    """(N, N_out, k) with the reference's constants as defaults (extract_lsm_features.py:10-16).  For another N
+    the defaults follow it the way the reference's own constants relate: k = int(0.10 * N * 2) (:16) and
+    N_out = 0.4 * N (400 of 1000, :10-11; the scaling BASELINE.json's larger configs use)."""
+    n = NUM_NEURONS if num_neurons is None else int(num_neurons)
+    if num_output_neurons is None:
+        n_out = NUM_OUTPUT_NEURONS if n == NUM_NEURONS else max(1, int(0.4 * n))
+    else:
+        n_out = int(num_output_neurons)
+    k = (SMALL_WORLD_K if n == NUM_NEURONS else int(0.10 * n * 2)) if small_world_k is None else int(small_world_k)
+    if not 1 <= n_out <= n:
+        raise ValueError(f"num_output_neurons={n_out} must lie in [1, num_neurons={n}]")
+    return n, n_out, k
+
+
+def _simulation_params(first_clip, leak_variance_divisor, num_neurons, num_output_neurons, small_world_k, seed):
+    from lsm_speech_classifier_amd.snn import SimulationParams
+    n, n_out, k = reservoir_shape(num_neurons, num_output_neurons, small_world_k)
+    kw = {} if seed is None else {"seed": int(seed)}
+    return SimulationParams(
+        num_neurons=n, mean_weight=0.0, num_output_neurons=n_out,
+        membrane_threshold=MEMBRANE_THRESHOLD, leak_coefficient=LEAK_COEFFICIENT,
+        refractory_period=REFRACTORY_PERIOD, small_world_graph_p=SMALL_WORLD_P,
+        small_world_graph_k=k, input_spike_times=first_clip,
+        leak_variance_divisor=leak_variance_divisor, **kw)
+
+
 def calculate_theoretical_w_critico(lsm_params, input_data):
     """Mean-field critical weight from the input spike density of the first <= 500 clips:
     (theta - 2 * density * refractory) / (k / 2); 0.007 when there is no data or k == 0."""
@@ -135,44 +162,61 @@ def run_network_diagnostics(lsm, X_sample_batch):
 
 
 def main_from_audio(audio, labels, n_filters: int, filterbank: str, feature_set: str, multiplier: float,
-                    leak_variance_divisor: float = None, batch: int = 1024):
+                    leak_variance_divisor: float = None, batch: int = 1024, *, num_neurons=None,
+                    num_output_neurons=None, small_world_k=None, seed=None):
     """Stages 1 + 2 without File 1: audio (n, 16000) float32 + labels -> File 2, the same arrays main() writes
     after create_dataset() (tests/test_gpu_hotpath.py compares them).  The split, w_critico (first <= 500
     training clips), the reservoir and the diagnostics follow main() line by line; the features come from
     `pipeline.HotPath`: every batch of clips goes filterbank -> encoder -> reservoir on the GPU, consecutive
-    batches overlapped on rotating streams, and no raster ever reaches the host.  Single process."""
+    batches overlapped on rotating streams, and no raster ever reaches the host.
+
+    Under a launcher the WHOLE path shards (the clip loops of create_dataset.py:143 and
+    extract_lsm_features.py:78 at once): every rank holds the clip list, encodes the same first <= 500
+    training clips for w_critico (so every rank builds the same reservoir), runs its contiguous
+    block of each split through its own HotPath on its own GPU, and the feature rows are all-gathered ONCE per
+    split; StandardScaler and the file stay on rank 0."""
     from sklearn.model_selection import train_test_split
     from sklearn.preprocessing import StandardScaler
-    from lsm_speech_classifier_amd import frontend, pipeline
-    from lsm_speech_classifier_amd.snn import SNN, SimulationParams
+    from lsm_speech_classifier_amd import dist as lsm_dist, frontend, pipeline
+    from lsm_speech_classifier_amd.snn import SNN
 
+    rank, _, world = lsm_dist.init()
     audio = np.ascontiguousarray(audio, dtype=np.float32)
     labels = np.asarray(labels, dtype=np.int32)
     if len(audio) == 0:
         print("Error: no audio clips")
+        lsm_dist.finish()
         return
     idx_train, idx_test, y_train, y_test = train_test_split(
         np.arange(len(audio)), labels, test_size=0.2, random_state=42, stratify=labels)
-    fe = frontend.SpikeFrontEnd(n_filters, filterbank)
+    dev = lsm_dist.local_device() if world > 1 else None
+    fe = frontend.SpikeFrontEnd(n_filters, filterbank, device=dev)
     head = fe.encode(audio[idx_train[:500]]).cpu().numpy()          # what w_critico and the diagnostics look at
-    params = SimulationParams(
-        num_neurons=NUM_NEURONS, mean_weight=0.0, num_output_neurons=NUM_OUTPUT_NEURONS,
-        membrane_threshold=MEMBRANE_THRESHOLD, leak_coefficient=LEAK_COEFFICIENT,
-        refractory_period=REFRACTORY_PERIOD, small_world_graph_p=SMALL_WORLD_P,
-        small_world_graph_k=SMALL_WORLD_K, input_spike_times=head[0],
-        leak_variance_divisor=leak_variance_divisor)
+    params = _simulation_params(head[0], leak_variance_divisor, num_neurons, num_output_neurons, small_world_k, seed)
     optimal_weight = calculate_theoretical_w_critico(params, head) * multiplier
     print(f"Using weight: {optimal_weight:.8f} (multiplier: {multiplier:.2f})")
     if leak_variance_divisor:
         print(f"Using Heterogeneous Leak. Divisor: {leak_variance_divisor}")
     params.mean_weight = optimal_weight
     params.weight_variance = WEIGHT_VARIANCE
-    lsm = SNN(simulation_params=params)
-    run_network_diagnostics(lsm, head)
+    lsm = SNN(simulation_params=params, device=dev)
+    if rank == 0:
+        run_network_diagnostics(lsm, head)
     keys = FEATURE_SETS[feature_set]
-    print(f"Extracting feature set: '{feature_set}' ({len(idx_train)} + {len(idx_test)} clips, audio -> features on the GPU)")
-    X_train_feat = pipeline.features_from_audio(audio[idx_train], fe, lsm, keys, batch=batch)
-    X_test_feat = pipeline.features_from_audio(audio[idx_test], fe, lsm, keys, batch=batch)
+    if rank == 0:
+        print(f"Extracting feature set: '{feature_set}' ({len(idx_train)} + {len(idx_test)} clips, audio -> features "
+              f"on the GPU" + (f", {world} ranks)" if world > 1 else ")"))
+
+    def split_features(idx):
+        lo, hi = lsm_dist.shard_range(len(idx), rank, world)
+        local = pipeline.features_from_audio(audio[idx[lo:hi]], fe, lsm, keys, batch=batch, device_out=True)
+        return lsm_dist.gather_rows(local, len(idx)).cpu().numpy()
+
+    X_train_feat = split_features(idx_train)
+    X_test_feat = split_features(idx_test)
+    lsm_dist.finish()
+    if rank != 0:
+        return
     scaler = StandardScaler()
     X_train_scaled = scaler.fit_transform(X_train_feat)
     X_test_scaled = scaler.transform(X_test_feat)
@@ -182,11 +226,14 @@ def main_from_audio(audio, labels, n_filters: int, filterbank: str, feature_set:
     print(f"Extraction complete. Features saved to '{FEATURE_FILE}'")
 
 
-def main(feature_set: str, multiplier: float, leak_variance_divisor: float = None):
+def main(feature_set: str, multiplier: float, leak_variance_divisor: float = None, *, num_neurons=None,
+         num_output_neurons=None, small_world_k=None, seed=None):
+    """The reference's three arguments; the keyword-only ones expose the module constants the reference
+    hard-codes (NUM_NEURONS, NUM_OUTPUT_NEURONS, SMALL_WORLD_K, the NumPy seed), None = the reference's value."""
     from sklearn.model_selection import train_test_split
     from sklearn.preprocessing import StandardScaler
     from lsm_speech_classifier_amd import dist as lsm_dist
-    from lsm_speech_classifier_amd.snn import SNN, SimulationParams
+    from lsm_speech_classifier_amd.snn import SNN
 
     rank, _, world = lsm_dist.init()
     X_spikes, y_labels = load_spike_dataset()
@@ -195,12 +242,7 @@ def main(feature_set: str, multiplier: float, leak_variance_divisor: float = Non
     X_train, X_test, y_train, y_test = train_test_split(
         X_spikes, y_labels, test_size=0.2, random_state=42, stratify=y_labels)
 
-    params = SimulationParams(
-        num_neurons=NUM_NEURONS, mean_weight=0.0, num_output_neurons=NUM_OUTPUT_NEURONS,
-        membrane_threshold=MEMBRANE_THRESHOLD, leak_coefficient=LEAK_COEFFICIENT,
-        refractory_period=REFRACTORY_PERIOD, small_world_graph_p=SMALL_WORLD_P,
-        small_world_graph_k=SMALL_WORLD_K, input_spike_times=X_train[0],
-        leak_variance_divisor=leak_variance_divisor)
+    params = _simulation_params(X_train[0], leak_variance_divisor, num_neurons, num_output_neurons, small_world_k, seed)
     optimal_weight = calculate_theoretical_w_critico(params, X_train) * multiplier
     print(f"Using weight: {optimal_weight:.8f} (multiplier: {multiplier:.2f})")
     if leak_variance_divisor:
@@ -208,7 +250,8 @@ def main(feature_set: str, multiplier: float, leak_variance_divisor: float = Non
     params.mean_weight = optimal_weight
     params.weight_variance = WEIGHT_VARIANCE
 
-    lsm = SNN(simulation_params=params)       # every rank builds the same wiring (same seed)
+    lsm = SNN(simulation_params=params,       # every rank builds the same wiring (same seed)
+              device=lsm_dist.local_device() if world > 1 else None)
     if rank == 0:
         run_network_diagnostics(lsm, X_train)
 
@@ -229,10 +272,24 @@ def main(feature_set: str, multiplier: float, leak_variance_divisor: float = Non
     print(f"Extraction complete. Features saved to '{FEATURE_FILE}'")
 
 
+def add_reservoir_flags(ap):
+    """extract_lsm_features.py:10-16,30 of the reference as flags (shared with main.py, which forwards them);
+    defaults reproduce the reference's constants."""
+    ap.add_argument("--num-neurons", type=int, default=None, help=f"Reservoir size (default {NUM_NEURONS}).")
+    ap.add_argument("--num-output-neurons", type=int, default=None,
+                    help=f"Read-out neurons (default {NUM_OUTPUT_NEURONS}; 0.4 * N for another N).")
+    ap.add_argument("--small-world-k", type=int, default=None,
+                    help="Ring neighbours of the small-world graph (default int(0.2 * N)).")
+    ap.add_argument("--seed", type=int, default=None, help="Seed of the reservoir wiring (default 42).")
+
+
 if __name__ == "__main__":
     ap = argparse.ArgumentParser(description="Extract features from a spike train dataset using an LSM.")
     ap.add_argument("--feature-set", type=str, default="original", choices=FEATURE_SETS.keys())
     ap.add_argument("--multiplier", type=float, default=0.6)
     ap.add_argument("--leak-variance-divisor", type=float, default=None)
+    add_reservoir_flags(ap)
     a = ap.parse_args()
-    main(feature_set=a.feature_set, multiplier=a.multiplier, leak_variance_divisor=a.leak_variance_divisor)
+    main(feature_set=a.feature_set, multiplier=a.multiplier, leak_variance_divisor=a.leak_variance_divisor,
+         num_neurons=a.num_neurons, num_output_neurons=a.num_output_neurons, small_world_k=a.small_world_k,
+         seed=a.seed)

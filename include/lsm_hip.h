@@ -54,6 +54,24 @@ int lsm_gammatone_spec_f64(const float *audio, int n_clips, int n_samples, const
                            int n_filters, int nwin, int hop, int ncols, double *spec_out,
                            double *db_out, int coef_flags, void *stream);
 
+/* The whole gammatone front end of one clip in ONE launch: replaces the per-clip body of the loop at
+ * create_dataset.py:143-157 -- audio_to_spectrogram (gammatone branch, :49-78: gtgram, dB, max-80 floor,
+ * min-max normalise with eps 1e-8, flat input -> zeros, scipy zoom(order=1) to time_bins columns, crop),
+ * convert_spectrogram_to_spikes_hysteresis (:81-98) and create_pure_redundancy (:101-104).  Same results,
+ * bit for bit, as lsm_gammatone_spec_f64 followed by lsm_spec_to_spikes_f64(apply_floor = 1), without the
+ * (n_clips, n_filters, ncols) float64 hand-off between two launches.
+ *   audio, coefs_dev, nwin/hop/ncols, coef_flags   as lsm_gammatone_spec_f64
+ *   thr_on/thr_off/n_thr/redundancy/raster         as lsm_spec_to_spikes_f64 (raster must not be NULL)
+ *   workspace   DEVICE scratch of at least lsm_gammatone_spikes_workspace(n_clips, n_filters, ncols) bytes,
+ *               8-byte aligned, owned by the caller, contents undefined before and after the call
+ * Returns LSM_ERR_UNSUPPORTED for more than 1024 filters (use the two split entry points). */
+long lsm_gammatone_spikes_workspace(int n_clips, int n_filters, int ncols);
+int lsm_gammatone_spikes_f64(const float *audio, int n_clips, int n_samples, const double *coefs_dev,
+                             int n_filters, int nwin, int hop, int ncols, int time_bins,
+                             const double *thr_on, const double *thr_off, int n_thr, int redundancy,
+                             uint8_t *raster, void *workspace, long workspace_bytes, int coef_flags,
+                             void *stream);
+
 /* Replaces create_dataset.py:60 (apply_floor: max-80 dB floor), :62-78 (min-max normalise with
  * eps 1e-8, flat input -> zeros, scipy zoom(order=1) to time_bins columns, crop), :81-98
  * (hysteresis encoder) and :101-104 (row repeat), one clip per workgroup.
@@ -119,13 +137,16 @@ int lsm_reservoir_destroy(lsm_reservoir *h);
 
 /* Kernel used by lsm_reservoir_run for this handle: 0 = choose (register accumulation over dense
  * presynaptic rows; over ring rows -- dense ring window + list of the synapses outside it -- for ring-like
- * reservoirs whose dense table exceeds the L2 caches), 1 = sparse CSC scatter through LDS, 2 = dense rows,
+ * reservoirs whose dense table exceeds the L2 caches), 1 = sparse CSC scatter through LDS, 2 = dense rows
+ * (for a reservoir that mode 0 serves with ring rows the dense table is built by THIS call: it allocates and
+ * synchronises, once),
  * 3 = ring rows (refused when the reservoir is not ring-like or has fewer than ~700 neurons), 4 = ring rows
  * restricted to the layouts with contiguous quad ownership (tests; 3 prefers the strided ones).  All produce
  * bit-identical results (SPEC.md §3).  num_neurons <= 8192. */
 int lsm_reservoir_set_kernel(lsm_reservoir *h, int mode);
 
-/* The kernel lsm_reservoir_run would launch for this handle now: 1 sparse, 2 dense rows, 3 ring rows. */
+/* The kernel lsm_reservoir_run would launch for this handle now: 1 sparse, 2 dense rows, 3 ring rows -- for the
+ * reference's 400 time steps and waves_per_clip = 0; lsm_reservoir_plan answers for any launch. */
 int lsm_reservoir_kernel_in_use(const lsm_reservoir *h);
 
 /* Replaces, for a whole batch, the per-clip loop body of extract_all_features
@@ -154,6 +175,15 @@ int lsm_reservoir_run(const lsm_reservoir *h, const uint8_t *spikes_u8, int n_cl
 /* Layout that lsm_reservoir_run would use: waves per clip, 64-neuron slots per lane, LDS bytes. */
 int lsm_reservoir_layout(const lsm_reservoir *h, int n_clips, int n_steps, int waves_per_clip,
                          int *wpc_out, int *slots_out, int *lds_bytes_out);
+
+/* The whole decision lsm_reservoir_run makes for (handle, batch, steps, waves_per_clip) -- run, layout and
+ * kernel_in_use all go through it: kernel (1 sparse, 2 dense rows, 3 ring rows), waves per clip, slots per lane,
+ * LDS bytes per clip, and the bytes of the weight table that kernel gathers its rows from (dense rows: N x ld x 4;
+ * ring rows: windows + this layout's lists; sparse: the CSC arrays).  Any out pointer may be NULL.  In auto mode a
+ * reservoir that prefers ring rows falls back to the dense (else sparse) kernel when no ring layout fits the LDS or
+ * offers the requested waves per clip; an explicit ring request (modes 3, 4) fails instead. */
+int lsm_reservoir_plan(const lsm_reservoir *h, int n_clips, int n_steps, int waves_per_clip, int *kernel_out,
+                       int *wpc_out, int *slots_out, int *lds_bytes_out, long *table_bytes_out);
 
 /* Diagnostic builds (-DLSM_STAMP=1) only: per-phase s_memtime sums of the reservoir kernel
  * (out8: 8 counters, HOST memory); all zeros in the shipped build. */

@@ -19,6 +19,9 @@ _SIGS = {
     "lsm_device_count": (c_int, []),
     "lsm_gammatone_spec_f64": (c_int, [c_void, c_int, c_int, c_void, c_int, c_int, c_int, c_int,
                                        c_void, c_void, c_int, c_void]),
+    "lsm_gammatone_spikes_workspace": (C.c_long, [c_int, c_int, c_int]),
+    "lsm_gammatone_spikes_f64": (c_int, [c_void, c_int, c_int, c_void, c_int, c_int, c_int, c_int, c_int,
+                                         c_void, c_void, c_int, c_int, c_void, c_void, C.c_long, c_int, c_void]),
     "lsm_spec_to_spikes_f64": (c_int, [c_void, c_int, c_int, c_int, c_int, c_int, c_void, c_void,
                                        c_int, c_int, c_void, c_void, c_void]),
     "lsm_spec_to_spikes_f32": (c_int, [c_void, c_int, c_int, c_int, c_int, c_int, c_void, c_void,
@@ -39,6 +42,8 @@ _SIGS = {
                                   c_void, c_void, c_int, c_void]),
     "lsm_reservoir_layout": (c_int, [c_void, c_int, c_int, c_int, C.POINTER(c_int),
                                      C.POINTER(c_int), C.POINTER(c_int)]),
+    "lsm_reservoir_plan": (c_int, [c_void, c_int, c_int, c_int, C.POINTER(c_int), C.POINTER(c_int),
+                                   C.POINTER(c_int), C.POINTER(c_int), C.POINTER(C.c_long)]),
     "lsm_debug_lif_stamps": (c_int, [c_void, c_int]),
 }
 

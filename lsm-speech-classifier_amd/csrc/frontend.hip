@@ -10,6 +10,7 @@
 #include "lsm_common.h"
 #include <cstdlib>
 #include <mutex>
+#include <type_traits>
 
 namespace {
 
@@ -289,6 +290,347 @@ __global__ __launch_bounds__(256) void spec_to_spikes_kernel(const SpikeArgs<T> 
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Fused front end: filterbank -> dB -> floor/min-max normalise -> linear resize -> hysteresis encoder ->
+// uint8 raster in ONE launch (create_dataset.py:49-104 per clip).  The filter loop is the one of
+// gammatone_kernel; what differs:
+//   * a wave carries NCH channel groups of its clip (NCH = 2: 128 channels, two independent float64
+//     dependency chains per lane that share the scalar sample loads and the float32 -> float64
+//     conversion), so at 128 filters ONE WAVE IS ONE CLIP and the clip's max/min need no other wave;
+//   * the clip's dB columns go to a private scratch, column-major per wave (64 consecutive doubles per
+//     store); the lane that wrote a value is the only one that reads it back, after the last window, when
+//     the clip's maximum is known.  A row's 98 float64 values do not fit the registers next to the filter
+//     state of two chains and 100 KB per clip do not fit the LDS four times per CU;
+//   * max/min: running per lane, xor-shuffles per wave, one LDS exchange when a clip spans several waves
+//     (the waves of a clip always share a workgroup);
+//   * normalise / SciPy-exact resize / 4-threshold latch: one lane per channel, arithmetic and comparison
+//     order of spec_to_spikes_kernel<double>; the raster rows of a wave are staged bit-packed in LDS and
+//     leave as coalesced 4-byte stores.
+// Waves beyond the batch (last workgroup) skip the filter loop but keep the barriers.
+// ---------------------------------------------------------------------------------------------
+struct FusedArgs {
+    const float *audio;
+    const double *coefs;
+    double *ws;                 // (n_clips, ncols, groups*NCH*64) float64 scratch
+    uint8_t *raster;            // (n_clips, n_filters*redundancy, time_bins*n_thr)
+    int n_clips, n_samples, n_filters, nwin, hop, ncols;
+    int time_bins, n_thr, redundancy, groups;
+    double on[MAX_THR], off[MAX_THR];
+};
+
+template <int NW, bool FAST, int NCH>
+__global__ __launch_bounds__(GT_MAX_WPB * 64) void gammatone_spikes_kernel(const FusedArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    double *xch = reinterpret_cast<double *>(smem);                       // 2 * GT_MAX_WPB doubles
+    uint32_t *stage_all = reinterpret_cast<uint32_t *>(smem + 2 * GT_MAX_WPB * sizeof(double));
+    const int lane = (int)(threadIdx.x & 63);
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int wpb = (int)(blockDim.x >> 6);
+    const int groups = a.groups;                                          // waves per clip
+    const int wid = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * wpb)) + wave;
+    const int b_raw = wid / groups;
+    const bool valid = b_raw < a.n_clips;
+    const int b = valid ? b_raw : a.n_clips - 1;
+    const int g = wid - b_raw * groups;
+    const int F = a.n_filters, nwin = a.nwin, hop = a.hop, ncols = a.ncols, n_samples = a.n_samples;
+    const int NG = groups * NCH;                                          // 64-channel groups per clip (padded)
+
+    bool live[NCH];
+    double b0[NCH], b11[NCH], b12[NCH], b13[NCH], b14[NCH], b2[NCH], a1[NCH], a2[NCH], gain[NCH], rgain[NCH];
+#pragma unroll
+    for (int q = 0; q < NCH; ++q) {
+        const int chl = (g * NCH + q) * 64 + lane;
+        live[q] = chl < F;
+        const double *k = a.coefs + (size_t)(live[q] ? chl : F - 1) * 10;
+        const double a0 = k[6];
+        b0[q] = k[0] / a0; b2[q] = k[5] / a0;
+        b11[q] = k[1] / a0; b12[q] = k[2] / a0; b13[q] = k[3] / a0; b14[q] = k[4] / a0;
+        a1[q] = k[7] / a0; a2[q] = k[8] / a0; gain[q] = k[9];
+        rgain[q] = 1.0 / gain[q];
+    }
+    const float *__restrict__ x = a.audio + (size_t)b * n_samples;        // wave-uniform
+
+    double z01[NCH], z11[NCH], z02[NCH], z12[NCH], z03[NCH], z13[NCH], z04[NCH], z14[NCH];
+    double win[NCH][NW];
+    double mx[NCH], mn[NCH];
+#pragma unroll
+    for (int q = 0; q < NCH; ++q) {
+        z01[q] = z11[q] = z02[q] = z12[q] = z03[q] = z13[q] = z04[q] = z14[q] = 0.0;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) win[q][w] = 0.0;
+        mx[q] = -INFINITY; mn[q] = INFINITY;
+    }
+
+    auto filt = [&](int q, double x0) __attribute__((always_inline)) -> double {
+        const double y1 = z01[q] + b0[q] * x0;
+        z01[q] = (z11[q] + x0 * b11[q]) - y1 * a1[q];
+        z11[q] = FAST ? -(y1 * a2[q]) : x0 * b2[q] - y1 * a2[q];
+        const double y2 = z02[q] + b0[q] * y1;
+        z02[q] = (z12[q] + y1 * b12[q]) - y2 * a1[q];
+        z12[q] = FAST ? -(y2 * a2[q]) : y1 * b2[q] - y2 * a2[q];
+        const double y3 = z03[q] + b0[q] * y2;
+        z03[q] = (z13[q] + y2 * b13[q]) - y3 * a1[q];
+        z13[q] = FAST ? -(y3 * a2[q]) : y2 * b2[q] - y3 * a2[q];
+        const double y4 = z04[q] + b0[q] * y3;
+        z04[q] = (z14[q] + y3 * b14[q]) - y4 * a1[q];
+        z14[q] = FAST ? -(y4 * a2[q]) : y3 * b2[q] - y4 * a2[q];
+        double o;
+        if (FAST) {
+            const double q0 = y4 * rgain[q];
+            o = __builtin_fma(__builtin_fma(-q0, gain[q], y4), rgain[q], q0);
+        } else {
+            o = y4 / gain[q];
+        }
+        return o * o;
+    };
+#define LSM_RUNF(n_to, NACT)                                                        \
+    {                                                                               \
+        if (n + 8 <= (n_to)) {                                                      \
+            float xs[8], nx[8];                                                     \
+            _Pragma("unroll") for (int u = 0; u < 8; ++u) xs[u] = x[n + u];         \
+            for (; n + 8 <= (n_to); n += 8) {                                       \
+                const float *pn = x + min(n + 8, n_samples - 8);                    \
+                _Pragma("unroll") for (int u = 0; u < 8; ++u) nx[u] = pn[u];        \
+                _Pragma("unroll") for (int u = 0; u < 8; ++u) {                     \
+                    const double x0 = (double)xs[u];                                \
+                    _Pragma("unroll") for (int q = 0; q < NCH; ++q) {               \
+                        const double e = filt(q, x0);                               \
+                        _Pragma("unroll") for (int w = 0; w < (NACT); ++w) win[q][w] += e; \
+                    }                                                               \
+                }                                                                   \
+                _Pragma("unroll") for (int u = 0; u < 8; ++u) xs[u] = nx[u];        \
+            }                                                                       \
+        }                                                                           \
+        for (; n < (n_to); ++n) {                                                   \
+            const double x0 = (double)x[n];                                         \
+            _Pragma("unroll") for (int q = 0; q < NCH; ++q) {                       \
+                const double e = filt(q, x0);                                       \
+                _Pragma("unroll") for (int w = 0; w < (NACT); ++w) win[q][w] += e;  \
+            }                                                                       \
+        }                                                                           \
+    }
+
+    // scratch of this wave: column c, chain q at wsw[(c * NG + q) * 64]
+    double *wsw = a.ws + ((size_t)b * ncols * NG + (size_t)g * NCH) * 64 + lane;
+    if (valid) {
+        const int pos = nwin - (NW - 1) * hop;
+        const int n_end = (ncols - 1) * hop + nwin;
+        const double dn = (double)nwin;
+        int n = 0;
+        for (int h = 0; n < n_end; ++h) {
+            const int base = h * hop;
+            const int mid = min(base + pos, n_end);
+            LSM_RUNF(mid, NW)
+            const int c = h - (NW - 1);
+            if (n == base + pos && c >= 0 && c < ncols) {
+#pragma unroll
+                for (int q = 0; q < NCH; ++q) {
+                    const double y = sqrt(win[q][NW - 1] / dn);
+                    const double v = 20 * log10(y + 1e-9);
+                    wsw[((size_t)c * NG + q) * 64] = v;
+                    if (live[q]) {
+                        mx[q] = v > mx[q] ? v : mx[q];
+                        mn[q] = v < mn[q] ? v : mn[q];
+                    }
+                }
+            }
+            const int stop = min(base + hop, n_end);
+            LSM_RUNF(stop, NW - 1)
+#pragma unroll
+            for (int q = 0; q < NCH; ++q) {
+#pragma unroll
+                for (int w = NW - 1; w > 0; --w) win[q][w] = win[q][w - 1];
+                win[q][0] = 0.0;
+            }
+        }
+    }
+#undef LSM_RUNF
+
+    // ---- the clip's max / min -----------------------------------------------------------------
+    double hi = mx[0], lo = mn[0];
+#pragma unroll
+    for (int q = 1; q < NCH; ++q) {
+        hi = mx[q] > hi ? mx[q] : hi;
+        lo = mn[q] < lo ? mn[q] : lo;
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        const double oh = __shfl_xor(hi, off), ol = __shfl_xor(lo, off);
+        hi = oh > hi ? oh : hi;
+        lo = ol < lo ? ol : lo;
+    }
+    if (groups > 1) {                                   // uniform over the launch
+        if (lane == 0) { xch[2 * wave] = hi; xch[2 * wave + 1] = lo; }
+        __syncthreads();
+        const int w0 = wave - g;                        // first wave of this clip in the workgroup
+        hi = xch[2 * w0]; lo = xch[2 * w0 + 1];
+        for (int i = 1; i < groups; ++i) {
+            const double oh = xch[2 * (w0 + i)], ol = xch[2 * (w0 + i) + 1];
+            hi = oh > hi ? oh : hi;
+            lo = ol < lo ? ol : lo;
+        }
+    }
+    // create_dataset.py:60 floors at max-80 before the min is taken: min' = max(min, max-80)
+    const double fl = hi - 80.0;
+    lo = lo > fl ? lo : fl;
+    const bool flat = (hi - lo) < 1e-8;
+    const double den = (hi - lo) + 1e-8;
+    const int Tb = a.time_bins, n_thr = a.n_thr;
+    const int row_bits = Tb * n_thr;
+    const double zf = (double)(ncols - 1) / (double)(Tb - 1);
+    // (x - lo) / den for 2 x 100 values per channel: den is wave-uniform, so its correctly rounded reciprocal is
+    // computed once and every quotient is q = x*r, q' = fma(fma(-q, den, x), r, q) -- Markstein's sequence, the
+    // correctly rounded quotient (= the IEEE division spec_to_spikes_kernel performs) unless den's significand is
+    // all ones or den leaves the normal range (broken audio: inf/NaN); those clips take the true division.  The
+    // numerators need no check of their own: every x is clamped into [lo, hi] (NaN and -inf become the floor), so
+    // 0 <= x - lo <= hi - lo < den, a difference of two dB values: zero or far above the denormal range.
+    const double rden = 1.0 / den;
+    const unsigned long long den_bits = (unsigned long long)__double_as_longlong(den);
+    const bool fastdiv = den > 1e-200 && den < 1e200 &&
+                         (den_bits & 0x000FFFFFFFFFFFFFull) != 0x000FFFFFFFFFFFFFull;
+    // Pass A (no dependency between bins, the loads of a whole group of bins in flight together): per bin j and
+    // threshold t the two comparisons the latch needs, S = val > on[t] in bit t and R = val < off[t] in bit FBH + t
+    // of the bin's field; JPW fields per LDS word of the lane's row.  Pass B (serial in j, LDS only) runs the
+    // set/reset latches of all thresholds at once, A = S | (A & ~R), and packs the raster bits IN PLACE: the
+    // raster word of bin j lies at or below the field word of bin j in the same row.  Fields of bins >= Tb in the
+    // last word repeat the last bin and are never read.
+    const int FBH = n_thr <= 4 ? 4 : 8;                 // bits per half field
+    const int JPW = 16 / FBH;                           // bins per 32-bit word (4 or 2)
+    const int BW = (Tb + JPW - 1) / JPW;                // words per lane row (>= raster words per row)
+    uint32_t *stage = stage_all + (size_t)wave * (NCH * 64) * BW;
+    const size_t cs = (size_t)NG * 64;                  // doubles between two columns of the scratch
+    // straight-line variants (fast division or not, <= 4 thresholds or not, resize or not): one uniform choice
+    // per wave instead of uniform branches inside the loop, which would keep the compiler from batching the loads
+    auto pass_a = [&](auto fast_c, auto nt_c, auto zoom_c) __attribute__((always_inline)) {
+        constexpr bool FD = decltype(fast_c)::value;
+        constexpr int NT = decltype(nt_c)::value;       // thresholds compared (tables are padded with +inf / -inf)
+        constexpr bool ZOOM = decltype(zoom_c)::value;
+        constexpr int H = NT <= 4 ? 4 : 8, G = 16 / H;  // = FBH, JPW
+        auto norm1 = [&](double v) __attribute__((always_inline)) -> double {
+            v = v > fl ? v : fl;
+            const double d = v - lo;
+            if (FD) {
+                const double q0 = d * rden;
+                return __builtin_fma(__builtin_fma(-q0, den, d), rden, q0);
+            }
+            return d / den;
+        };
+        for (int jw = 0; jw < BW; ++jw) {
+            double x0[G][NCH], x1[G][NCH], w0[G], w1[G];
+            bool two[G];
+#pragma unroll
+            for (int u = 0; u < G; ++u) {
+                const int j = min(jw * G + u, Tb - 1);
+                // scipy.ndimage.zoom(order=1): double coordinate and weights, w1 = 1 - w0
+                const double cc = (double)j * zf;
+                const double fc = floor(cc);
+                const int f = ZOOM ? (int)fc : j;
+                w0[u] = 1.0 - (cc - fc);
+                w1[u] = 1.0 - w0[u];
+                two[u] = f + 1 <= ncols - 1;
+                const int f1 = two[u] ? f + 1 : f;
+#pragma unroll
+                for (int q = 0; q < NCH; ++q) {
+                    const double *col = wsw + (size_t)q * 64;
+                    x0[u][q] = col[(size_t)f * cs];
+                    if (ZOOM) x1[u][q] = col[(size_t)f1 * cs];
+                }
+            }
+            uint32_t fw[NCH];
+#pragma unroll
+            for (int q = 0; q < NCH; ++q) fw[q] = 0u;
+#pragma unroll
+            for (int u = 0; u < G; ++u) {
+#pragma unroll
+                for (int q = 0; q < NCH; ++q) {
+                    const double n0 = norm1(x0[u][q]);
+                    double val = n0;
+                    if (ZOOM) {
+                        const double n1 = norm1(x1[u][q]);
+                        const double acc = n0 * w0[u];
+                        // the last column has no right neighbour; its weight w1 is 0 there and, on the fast path,
+                        // n1 is finite and acc >= +0, so acc + n1*0 == acc bit for bit: no branch needed
+                        val = (FD || two[u]) ? acc + n1 * w1[u] : acc;
+                    }
+                    val = flat ? 0.0 : val;
+                    uint32_t field = 0u;
+#pragma unroll
+                    for (int t = 0; t < NT; ++t) {
+                        field |= (val > a.on[t] ? 1u : 0u) << t;
+                        field |= (val < a.off[t] ? 1u : 0u) << (H + t);
+                    }
+                    fw[q] |= field << (u * 2 * H);
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < NCH; ++q) stage[(q * 64 + lane) * BW + jw] = fw[q];
+        }
+    };
+    {
+        using T = std::true_type;
+        using F = std::false_type;
+        using N4 = std::integral_constant<int, 4>;
+        using N8 = std::integral_constant<int, MAX_THR>;
+        const bool zoom = ncols != Tb;
+        if (n_thr <= 4) {
+            if (fastdiv) { if (zoom) pass_a(T{}, N4{}, T{}); else pass_a(T{}, N4{}, F{}); }
+            else         { if (zoom) pass_a(F{}, N4{}, T{}); else pass_a(F{}, N4{}, F{}); }
+        } else {
+            if (fastdiv) { if (zoom) pass_a(T{}, N8{}, T{}); else pass_a(T{}, N8{}, F{}); }
+            else         { if (zoom) pass_a(F{}, N8{}, T{}); else pass_a(F{}, N8{}, F{}); }
+        }
+    }
+    // Pass B: the lane's own rows only, so no barrier: LDS serves one wave's accesses in order
+    const uint32_t tmask = (1u << n_thr) - 1u;
+#pragma unroll
+    for (int q = 0; q < NCH; ++q) {
+        uint32_t *srow = stage + (q * 64 + lane) * BW;
+        uint32_t act = 0u, cur = 0u;
+        unsigned long long acc = 0ull;
+        int fill = 0, wout = 0;
+        for (int j = 0; j < Tb; ++j) {
+            const int u = j % JPW;
+            if (u == 0) cur = srow[j / JPW];
+            const uint32_t field = cur >> (u * 2 * FBH);
+            const uint32_t S = field & tmask, R = (field >> FBH) & tmask;
+            act = S | (act & ~R);
+            acc |= (unsigned long long)act << fill;
+            fill += n_thr;
+            if (fill >= 32) {
+                srow[wout++] = (uint32_t)acc;
+                acc >>= 32;
+                fill -= 32;
+            }
+        }
+        if (fill > 0) srow[wout] = (uint32_t)acc;
+    }
+    __syncthreads();                                    // the wave's own staged rows (and a uniform barrier count)
+    if (valid) {
+        // create_pure_redundancy: output row c reads filter row c / redundancy
+        const int R = a.redundancy;
+        const int fbase = g * NCH * 64;
+        const int rows_out = min(NCH * 64, F - fbase) * R;
+        const int row_bytes = row_bits;
+        uint8_t *dst = a.raster + ((size_t)b * F + fbase) * R * row_bytes;
+        if ((row_bytes & 3) == 0) {
+            const int rw = row_bytes >> 2;
+            uint32_t *d4 = reinterpret_cast<uint32_t *>(dst);
+            for (int i = lane; i < rows_out * rw; i += 64) {
+                const int c = i / rw;
+                const int p = (i - c * rw) * 4;
+                const uint32_t nib = (stage[(c / R) * BW + (p >> 5)] >> (p & 31)) & 0xFu;
+                d4[i] = (nib * 0x00204081u) & 0x01010101u;
+            }
+        } else {
+            for (int i = lane; i < rows_out * row_bytes; i += 64) {
+                const int c = i / row_bytes;
+                const int p = i - c * row_bytes;
+                dst[i] = (uint8_t)((stage[(c / R) * BW + (p >> 5)] >> (p & 31)) & 1u);
+            }
+        }
+    }
+}
+
 // Stand-alone encoder on an already normalised spectrogram (B, F, n_bins): one lane per channel.
 template <typename T>
 __global__ __launch_bounds__(64) void encode_kernel(const T *__restrict__ spec, int n_rows,
@@ -501,6 +843,113 @@ LSM_API int lsm_gammatone_spec_f64(const float *audio, int n_clips, int n_sample
     default: LSM_GT(4) break;
     }
 #undef LSM_GT
+    LSM_CHECK_HIP(hipGetLastError());
+    return LSM_OK;
+}
+
+// Layout of the fused launch for `n_filters`: chains per lane, waves per clip, waves per workgroup.
+struct FusedPlan { int nch, groups, wpb; };
+static bool fused_plan(int n_filters, FusedPlan *p)
+{
+    int nch = n_filters > 64 ? 2 : 1;
+#if LSM_EXPERIMENT_HOOKS
+    static const int nch_env = [] { const char *e = getenv("LSM_GTF_NCH"); return e ? atoi(e) : 0; }();
+    if (nch_env == 1 || nch_env == 2) nch = nch_env;
+#endif
+    const int groups = (n_filters + 64 * nch - 1) / (64 * nch);
+    if (groups > GT_MAX_WPB) return false;
+    int wpb = groups >= 4 ? groups : groups * (4 / groups);     // a multiple of `groups`, about 4 waves
+#if LSM_EXPERIMENT_HOOKS
+    static const int wpb_env = [] { const char *e = getenv("LSM_GTF_WPB"); return e ? atoi(e) : 0; }();
+    if (wpb_env >= 1 && wpb_env <= GT_MAX_WPB && wpb_env % groups == 0) wpb = wpb_env;
+#endif
+    p->nch = nch; p->groups = groups; p->wpb = wpb;
+    return true;
+}
+
+LSM_API long lsm_gammatone_spikes_workspace(int n_clips, int n_filters, int ncols)
+{
+    if (n_clips < 0 || n_filters < 1 || ncols < 1) return 0;
+    // 64-channel groups padded to an even number: covers both the one- and the two-chain layout
+    return (long)n_clips * ncols * (((n_filters + 127) / 128) * 2) * 64 * (long)sizeof(double);
+}
+
+LSM_API int lsm_gammatone_spikes_f64(const float *audio, int n_clips, int n_samples,
+                                     const double *coefs, int n_filters, int nwin, int hop, int ncols,
+                                     int time_bins, const double *thr_on, const double *thr_off, int n_thr,
+                                     int redundancy, uint8_t *raster, void *workspace, long workspace_bytes,
+                                     int coef_flags, void *stream)
+{
+    LSM_REQUIRE(n_clips >= 0 && n_filters >= 1 && n_samples >= 1, "bad shape");
+    LSM_REQUIRE(nwin >= 1 && hop >= 1 && ncols >= 2 && time_bins >= 2, "bad window");
+    LSM_REQUIRE(nwin <= NWIN_MAX * hop, "nwin=%d needs more than %d overlapping windows of hop=%d",
+                nwin, NWIN_MAX, hop);
+    LSM_REQUIRE((long)(ncols - 1) * hop + nwin <= n_samples, "columns exceed the clip");
+    LSM_REQUIRE(n_samples >= 8, "clips shorter than 8 samples are not supported");
+    LSM_REQUIRE(n_thr >= 1 && n_thr <= MAX_THR, "n_thr=%d outside [1, %d]", n_thr, MAX_THR);
+    LSM_REQUIRE(redundancy >= 1, "redundancy must be >= 1");
+    LSM_REQUIRE(thr_on && thr_off, "null threshold table");
+    if (n_clips == 0) return LSM_OK;
+    LSM_REQUIRE(audio && coefs && raster && workspace, "gammatone_spikes: null buffer");
+    LSM_REQUIRE(workspace_bytes >= lsm_gammatone_spikes_workspace(n_clips, n_filters, ncols),
+                "workspace of %ld bytes, need %ld (lsm_gammatone_spikes_workspace)", workspace_bytes,
+                lsm_gammatone_spikes_workspace(n_clips, n_filters, ncols));
+    LSM_REQUIRE(((uintptr_t)workspace & 7u) == 0, "workspace must be 8-byte aligned");
+    const int row_bytes = time_bins * n_thr;
+    LSM_REQUIRE((row_bytes & 3) != 0 || ((uintptr_t)raster & 3u) == 0,
+                "the raster must be 4-byte aligned when a row is a multiple of 4 bytes");
+    FusedPlan pl;
+    if (!fused_plan(n_filters, &pl)) {
+        lsm_set_error("gammatone_spikes: %d filters need more than %d waves per clip; use the split entry points",
+                      n_filters, GT_MAX_WPB);
+        return LSM_ERR_UNSUPPORTED;
+    }
+    FusedArgs a;
+    a.audio = audio; a.coefs = coefs; a.ws = static_cast<double *>(workspace); a.raster = raster;
+    a.n_clips = n_clips; a.n_samples = n_samples; a.n_filters = n_filters; a.nwin = nwin; a.hop = hop;
+    a.ncols = ncols; a.time_bins = time_bins; a.n_thr = n_thr; a.redundancy = redundancy; a.groups = pl.groups;
+    // unused table entries never fire: nothing is > +inf or < -inf (the kernel compares 4 or 8 thresholds)
+    for (int q = 0; q < MAX_THR; ++q) { a.on[q] = q < n_thr ? thr_on[q] : INFINITY; a.off[q] = q < n_thr ? thr_off[q] : -INFINITY; }
+    const long n_waves = (long)pl.groups * n_clips;
+    const long n_wgs = (n_waves + pl.wpb - 1) / pl.wpb;
+    LSM_REQUIRE(n_wgs <= 0x7fffffffL, "too many clips for one launch");
+    // per lane row: the comparison fields of pass A (4 bins per word up to 4 thresholds, else 2), reused for the raster bits
+    const int BW = n_thr <= 4 ? (time_bins + 3) / 4 : (time_bins + 1) / 2;
+    long lds = 2 * GT_MAX_WPB * (long)sizeof(double) + (long)pl.wpb * pl.nch * 64 * BW * 4;
+    LSM_REQUIRE(lds <= 160 * 1024, "raster stage of %ld bytes exceeds one CU's LDS", lds);
+    // CU-exclusive placement of small launches, as in lsm_gammatone_spec_f64
+    {
+        const DevInfo di = dev_info();
+        long resv = di.lds_per_cu / 2 + 1024;
+#if LSM_EXPERIMENT_HOOKS
+        static const long lds_env = [] { const char *e = getenv("LSM_GTF_LDS"); return e ? atol(e) : -1L; }();
+        if (lds_env >= 0) resv = lds_env;
+#endif
+        if (di.cus > 0 && n_wgs <= di.cus && di.lds_per_cu >= 4096 && resv > lds && resv <= di.lds_per_cu)
+            lds = resv;
+    }
+    const dim3 grid((unsigned)n_wgs), block((unsigned)(64 * pl.wpb));
+    const bool fast = (coef_flags & 3) == 3;
+    const int nw = (nwin + hop - 1) / hop;
+#define LSM_GTF2(NW, FAST, NCH)                                                               \
+    {                                                                                         \
+        auto fn = gammatone_spikes_kernel<NW, FAST, NCH>;                                     \
+        if (lds > 64 * 1024) lsm_allow_big_lds(reinterpret_cast<const void *>(fn));           \
+        hipLaunchKernelGGL(fn, grid, block, (size_t)lds, (hipStream_t)stream, a);             \
+    }
+#define LSM_GTF(NW)                                                                           \
+    {                                                                                         \
+        if (fast) { if (pl.nch == 2) LSM_GTF2(NW, true, 2) else LSM_GTF2(NW, true, 1) }       \
+        else      { if (pl.nch == 2) LSM_GTF2(NW, false, 2) else LSM_GTF2(NW, false, 1) }     \
+    }
+    switch (nw) {
+    case 1: LSM_GTF(1) break;
+    case 2: LSM_GTF(2) break;
+    case 3: LSM_GTF(3) break;
+    default: LSM_GTF(4) break;
+    }
+#undef LSM_GTF
+#undef LSM_GTF2
     LSM_CHECK_HIP(hipGetLastError());
     return LSM_OK;
 }

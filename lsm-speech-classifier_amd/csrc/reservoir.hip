@@ -49,6 +49,7 @@ struct Variant {            // per waves-per-clip layout
 struct RingVariant {        // per waves-per-clip layout of the ring-row kernel (lif_ring.h)
     int wpc = 0, ql = 0, einw = 0;
     bool strided = false;            // quad ownership: wave w owns quads w, w+wpc, ... (else w*ql .. w*ql+ql-1)
+    size_t n_rem = 0;                // list entries (synapses outside the ring window)
     uint32_t *rem_ptr = nullptr;     // (N*wpc + 1) first list entry of (row, wave)
     uint2 *rem = nullptr;            // synapses outside the ring window: {LDS byte offset of the accumulator, weight bits}
     float *leak = nullptr;
@@ -57,6 +58,18 @@ struct RingVariant {        // per waves-per-clip layout of the ring-row kernel 
 };
 
 }  // namespace
+
+// Dense presynaptic rows from the device copy of the CSC arrays: block j scatters column j into row j.
+__global__ __launch_bounds__(256) void build_dense_rows_kernel(const uint32_t *__restrict__ rowptr,
+                                                               const uint2 *__restrict__ syn, int ld,
+                                                               float *__restrict__ wt)
+{
+    const uint32_t j = blockIdx.x;
+    for (uint32_t e = rowptr[j] + threadIdx.x; e < rowptr[j + 1]; e += blockDim.x) {
+        const uint2 s = syn[e];
+        wt[(size_t)j * ld + s.x] = __uint_as_float(s.y);
+    }
+}
 
 struct lsm_reservoir {
     int N = 0, C = 0, n_out = 0, refractory = 0, burst_isi_max = 0;
@@ -101,6 +114,45 @@ static int free_reservoir(lsm_reservoir *h)
         if (v.in_ent) (void)hipFree(v.in_ent);
     }
     delete h;
+    return LSM_OK;
+}
+
+static bool has_ring(const lsm_reservoir *h)
+{
+    for (const auto &v : h->rvar)
+        if (v.wpc) return true;
+    return false;
+}
+
+// ring rows: on request, or by default when the dense table no longer fits the XCDs' L2 caches together
+// (32 MB) -- from there on the dense rows are bound by the bytes of the row gathers, of which the ring
+// format moves a quarter (N = 4000: window 3.6 KB + list 0.6 KB against 16 KB per row)
+constexpr size_t RING_AUTO_MIN_DENSE_BYTES = (size_t)32 << 20;
+
+// Allocate and fill the dense row table of a handle that does not have it yet (synchronous: handle set-up, not a
+// launch function).
+static int ensure_dense_rows(lsm_reservoir *h)
+{
+    if (h->wt || h->ld <= 0) return LSM_OK;
+    int dev_now = -1;
+    LSM_CHECK_HIP(hipGetDevice(&dev_now));
+    LSM_REQUIRE(dev_now == h->device, "reservoir handle lives on device %d but the current device is %d",
+                h->device, dev_now);
+    const size_t bytes = (size_t)h->N * (size_t)h->ld * sizeof(float);
+    float *wt = nullptr;
+    LSM_CHECK_HIP(hipMalloc(reinterpret_cast<void **>(&wt), bytes));
+    hipError_t e = hipMemset(wt, 0, bytes);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(build_dense_rows_kernel, dim3(h->N), dim3(256), 0, nullptr, h->rowptr, h->syn, h->ld, wt);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipDeviceSynchronize();
+    if (e != hipSuccess) {
+        (void)hipFree(wt);
+        lsm_set_error("building the dense row table failed: %s", hipGetErrorString(e));
+        return LSM_ERR_HIP;
+    }
+    h->wt = wt;
     return LSM_OK;
 }
 
@@ -231,18 +283,11 @@ int lsm_reservoir_create(lsm_reservoir **out, int num_neurons, int n_channels,
         }
         v.wpc = wpc; v.sl = sl; v.einw = einw;
     }
-    // dense presynaptic rows for the register-accumulating kernel (lif_dense.h): N x ld floats, only
-    // up to N = 8192 (4 MB at N = 1000: L2; 64 MB at N = 4000 and 262 MB at N = 8000: Infinity Cache / HBM)
-    {
-        int ldmax = 0;
-        for (const auto &v : h->var)
-            if (v.wpc) ldmax = std::max(ldmax, v.sl * 64 * v.wpc);
-        std::vector<float> wt((size_t)N * ldmax, 0.0f);
-        for (int j = 0; j < N; ++j)
-            for (int e = csc_ptr[j]; e < csc_ptr[j + 1]; ++e) wt[(size_t)j * ldmax + csc_post[e]] = csc_w[e];
-        if ((rc = upload(&h->wt, wt))) { free_reservoir(h); return rc; }
-        h->ld = ldmax;
-    }
+    // dense presynaptic rows for the register-accumulating kernel (lif_dense.h): N x ld floats (4 MB at N = 1000:
+    // L2; 64 MB at N = 4000 and 262 MB at N = 8000).  Built further down, and only when auto mode can run them
+    // (ensure_dense_rows); a reservoir that auto mode serves with ring rows gets them on lsm_reservoir_set_kernel(2).
+    for (const auto &v : h->var)
+        if (v.wpc) h->ld = std::max(h->ld, v.sl * 64 * v.wpc);
     // Ring rows for ring-like graphs (lif_ring.h): window half-width H = half the mean out-degree (k/2 of a
     // small-world graph).  Row j covers the targets from the 32-aligned start of (j-H) mod N up to (j+H) mod N
     // along the ring padded to NQ quads of 256.  Offered when the plain window holds most of the synapses and is
@@ -354,20 +399,19 @@ int lsm_reservoir_create(lsm_reservoir **out, int num_neurons, int n_channels,
                         free_reservoir(h);
                         return rc;
                     }
-                    v.wpc = wpc; v.ql = ql; v.einw = einw; v.strided = strided;
+                    v.wpc = wpc; v.ql = ql; v.einw = einw; v.strided = strided; v.n_rem = rptr.back();
                 }
             }
         }
     }
+    // dense rows now, unless the table exceeds the L2 caches AND ring rows exist: auto mode then never launches
+    // the dense kernel (it falls back to the sparse one when no ring layout fits), so the 64-262 MB table and its
+    // upload would be dead weight next to the ring table
+    if (!(has_ring(h) && (size_t)N * (size_t)h->ld * 4 > RING_AUTO_MIN_DENSE_BYTES)) {
+        if ((rc = ensure_dense_rows(h))) { free_reservoir(h); return rc; }
+    }
     *out = h;
     return LSM_OK;
-}
-
-static bool has_ring(const lsm_reservoir *h)
-{
-    for (const auto &v : h->rvar)
-        if (v.wpc) return true;
-    return false;
 }
 
 // 0 = choose, 1 = sparse CSC kernel, 2 = dense-row kernel, 3 = ring-row kernel.
@@ -377,7 +421,11 @@ int lsm_reservoir_set_kernel(lsm_reservoir *h, int mode)
     LSM_REQUIRE(h != nullptr, "lsm_reservoir_set_kernel: null handle");
     LSM_REQUIRE(mode >= 0 && mode <= 4, "mode must be 0 (auto), 1 (sparse), 2 (dense), 3 (ring) or 4 (ring, contiguous quads)");
     LSM_REQUIRE(mode < 3 || has_ring(h), "this reservoir has no ring-row format (not ring-like, or too small)");
-    LSM_REQUIRE(mode != 2 || h->wt != nullptr, "this reservoir has no dense row table");
+    if (mode == 2) {                       // an explicit request builds the table a ring-served reservoir deferred
+        const int rc = ensure_dense_rows(h);
+        if (rc) return rc;
+        LSM_REQUIRE(h->wt != nullptr, "this reservoir has no dense row table");
+    }
     h->mode = mode;
     return LSM_OK;
 }
@@ -444,10 +492,6 @@ static const RingVariant *choose_ring(const lsm_reservoir *h, int T, int request
     return best;
 }
 
-// ring rows: on request, or by default when the dense table no longer fits the XCDs' L2 caches together
-// (32 MB) -- from there on the dense rows are bound by the bytes of the row gathers, of which the ring
-// format moves a quarter (N = 4000: window 3.6 KB + list 0.6 KB against 16 KB per row)
-constexpr size_t RING_AUTO_MIN_DENSE_BYTES = (size_t)32 << 20;
 static bool want_ring(const lsm_reservoir *h)
 {
     if (!has_ring(h)) return false;
@@ -497,6 +541,33 @@ static const Variant *choose_variant(const lsm_reservoir *h, int B, int T, int r
     return best;
 }
 
+// ONE decision for lsm_reservoir_run, lsm_reservoir_layout, lsm_reservoir_plan and lsm_reservoir_kernel_in_use:
+// which kernel and which layout serve (handle, batch, steps, waves_per_clip).  Auto mode prefers ring rows for
+// large ring-like reservoirs but FALLS THROUGH to the dense (else sparse) kernel when no ring layout fits -- the
+// per-clip LDS image exceeds 160 KB (e.g. N = 8000 with 5000 output neurons: 175.7 KB as ring rows, 158.8 KB
+// for the dense/sparse layouts) or the reservoir's ring layouts lack the requested waves per clip.
+// Only an explicit ring request (modes 3, 4) is a hard error then.
+struct RunPlan {
+    int kernel = 0;                   // 1 sparse, 2 dense rows, 3 ring rows
+    const RingVariant *rv = nullptr;
+    const Variant *v = nullptr;
+};
+
+static int make_plan(const lsm_reservoir *h, int n_clips, int n_steps, int waves_per_clip, RunPlan *p)
+{
+    if (want_ring(h)) {
+        p->rv = choose_ring(h, n_steps, waves_per_clip > 0 ? waves_per_clip : 0);
+        if (p->rv) { p->kernel = 3; return LSM_OK; }
+        LSM_REQUIRE(h->mode < 3, "no ring-row layout for waves_per_clip=%d (N=%d, n_out=%d, T=%d): none fits a CU's "
+                    "160 KB of LDS or has that many waves", waves_per_clip, h->N, h->n_out, n_steps);
+    }
+    p->v = choose_variant(h, n_clips, n_steps, waves_per_clip);
+    LSM_REQUIRE(p->v != nullptr, "no reservoir layout for waves_per_clip=%d (N=%d, n_out=%d, T=%d)",
+                waves_per_clip, h->N, h->n_out, n_steps);
+    p->kernel = use_dense(h) ? 2 : 1;
+    return LSM_OK;
+}
+
 extern "C" __attribute__((visibility("default")))
 int lsm_reservoir_run(const lsm_reservoir *h, const uint8_t *spikes_u8, int n_clips, int n_steps,
                       const int32_t *key_ids, int n_keys, float *features_out,
@@ -517,10 +588,13 @@ int lsm_reservoir_run(const lsm_reservoir *h, const uint8_t *spikes_u8, int n_cl
         LSM_REQUIRE(key_ids[k] >= 0 && key_ids[k] < 8, "key id %d out of range", key_ids[k]);
     const size_t cw = (size_t)(h->C + 31) / 32;
 
-    if (want_ring(h)) {
-        const RingVariant *rv = choose_ring(h, n_steps, waves_per_clip > 0 ? waves_per_clip : 0);
-        LSM_REQUIRE(rv != nullptr, "no ring-row layout for waves_per_clip=%d (N=%d, T=%d)", waves_per_clip, h->N,
-                    n_steps);
+    RunPlan plan;
+    {
+        const int prc = make_plan(h, n_clips, n_steps, waves_per_clip, &plan);
+        if (prc) return prc;
+    }
+    if (plan.kernel == 3) {
+        const RingVariant *rv = plan.rv;
         const bool inreg = rv->einw <= IN_REG_SLOTS * 64;
         lsm_lif::ring_fn_t rfn = rv->ql == 1   ? lsm_lif::pick_ring_1(rv->wpc, inreg, rv->strided)
                                  : rv->ql == 2 ? lsm_lif::pick_ring_2(rv->wpc, inreg, rv->strided)
@@ -544,12 +618,8 @@ int lsm_reservoir_run(const lsm_reservoir *h, const uint8_t *spikes_u8, int n_cl
         LSM_CHECK_HIP(hipGetLastError());
         return LSM_OK;
     }
-    LSM_REQUIRE(h->mode < 3, "no ring-row layout for this reservoir");
-
-    const Variant *v = choose_variant(h, n_clips, n_steps, waves_per_clip);
-    LSM_REQUIRE(v != nullptr, "no reservoir layout for waves_per_clip=%d (N=%d, T=%d)",
-                waves_per_clip, h->N, n_steps);
-    if (use_dense(h)) {
+    const Variant *v = plan.v;
+    if (plan.kernel == 2) {
         lsm_lif::dense_fn_t dfn = v->inmask       ? lsm_lif::pick_dense_2(v->sl, v->wpc)
                                   : lif_inreg(*v) ? lsm_lif::pick_dense_1(v->sl, v->wpc)
                                                   : lsm_lif::pick_dense_0(v->sl, v->wpc);
@@ -595,35 +665,54 @@ int lsm_reservoir_run(const lsm_reservoir *h, const uint8_t *spikes_u8, int n_cl
     return LSM_OK;
 }
 
-// Introspection for tests and the bench: layout chosen for a batch, LDS bytes per workgroup.
+// Introspection for tests and the bench: kernel and layout chosen for a batch, LDS bytes per workgroup, bytes of the
+// weight table the kernel gathers its rows from.
+extern "C" __attribute__((visibility("default")))
+int lsm_reservoir_plan(const lsm_reservoir *h, int n_clips, int n_steps, int waves_per_clip, int *kernel_out,
+                       int *wpc_out, int *slots_out, int *lds_bytes_out, long *table_bytes_out)
+{
+    LSM_REQUIRE(h != nullptr, "lsm_reservoir_plan: null handle");
+    LSM_REQUIRE(n_clips >= 0 && n_steps >= 1 && n_steps <= 65535, "bad n_clips/n_steps");
+    LSM_REQUIRE(waves_per_clip >= -1 && waves_per_clip <= 16, "waves_per_clip must be -1 (pipelined), 0 (choose) or 1..16");
+    RunPlan p;
+    const int rc = make_plan(h, n_clips, n_steps, waves_per_clip, &p);
+    if (rc) return rc;
+    if (kernel_out) *kernel_out = p.kernel;
+    if (p.kernel == 3) {
+        if (wpc_out) *wpc_out = p.rv->wpc;
+        if (slots_out) *slots_out = p.rv->ql * 4;
+        if (lds_bytes_out) *lds_bytes_out = (int)ring_lds_bytes(h, *p.rv, n_steps);
+        if (table_bytes_out) {
+            // ring windows + this layout's lists of the synapses outside them + their row pointers
+            *table_bytes_out = (long)((size_t)h->N * h->band_pitch + p.rv->n_rem * 8 + ((size_t)h->N * p.rv->wpc + 1) * 4);
+        }
+        return LSM_OK;
+    }
+    if (wpc_out) *wpc_out = p.v->wpc;
+    if (slots_out) *slots_out = p.v->sl;
+    if (lds_bytes_out)
+        *lds_bytes_out = (int)(p.kernel == 2 ? dense_lds_bytes(h, *p.v, n_steps) : lif_lds_bytes(h, *p.v, n_steps));
+    if (table_bytes_out)
+        *table_bytes_out = p.kernel == 2 ? (long)((size_t)h->N * h->ld * 4) : (long)(h->nnz * 8 + ((size_t)h->N + 1) * 4);
+    return LSM_OK;
+}
+
 extern "C" __attribute__((visibility("default")))
 int lsm_reservoir_layout(const lsm_reservoir *h, int n_clips, int n_steps, int waves_per_clip,
                          int *wpc_out, int *slots_out, int *lds_bytes_out)
 {
-    LSM_REQUIRE(h != nullptr, "lsm_reservoir_layout: null handle");
-    if (want_ring(h)) {
-        const RingVariant *rv = choose_ring(h, n_steps, waves_per_clip > 0 ? waves_per_clip : 0);
-        LSM_REQUIRE(rv != nullptr, "no ring-row layout for waves_per_clip=%d", waves_per_clip);
-        if (wpc_out) *wpc_out = rv->wpc;
-        if (slots_out) *slots_out = rv->ql * 4;
-        if (lds_bytes_out) *lds_bytes_out = (int)ring_lds_bytes(h, *rv, n_steps);
-        return LSM_OK;
-    }
-    const Variant *v = choose_variant(h, n_clips, n_steps, waves_per_clip);
-    LSM_REQUIRE(v != nullptr, "no reservoir layout for waves_per_clip=%d", waves_per_clip);
-    if (wpc_out) *wpc_out = v->wpc;
-    if (slots_out) *slots_out = v->sl;
-    if (lds_bytes_out)
-        *lds_bytes_out = (int)(use_dense(h) ? dense_lds_bytes(h, *v, n_steps) : lif_lds_bytes(h, *v, n_steps));
-    return LSM_OK;
+    return lsm_reservoir_plan(h, n_clips, n_steps, waves_per_clip, nullptr, wpc_out, slots_out, lds_bytes_out, nullptr);
 }
 
-// Which kernel lsm_reservoir_run would launch for this handle: 1 sparse, 2 dense rows, 3 ring rows.
+// Which kernel lsm_reservoir_run would launch for this handle: 1 sparse, 2 dense rows, 3 ring rows -- for the
+// reference's 400 time steps and waves_per_clip = 0 (lsm_reservoir_plan answers for any launch).
 extern "C" __attribute__((visibility("default")))
 int lsm_reservoir_kernel_in_use(const lsm_reservoir *h)
 {
     if (h == nullptr) return LSM_ERR_ARG;
-    return want_ring(h) ? 3 : (use_dense(h) ? 2 : 1);
+    RunPlan p;
+    if (make_plan(h, 1, 400, 0, &p) != LSM_OK) return want_ring(h) ? 3 : (use_dense(h) ? 2 : 1);
+    return p.kernel;
 }
 
 // Diagnostic builds (-DLSM_STAMP=1) only: per-phase cycle sums of the LIF kernel; zeros otherwise.

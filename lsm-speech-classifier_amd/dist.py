@@ -22,19 +22,33 @@ def env_world():
 
 
 def init(backend: str | None = None):
-    """Join the process group when launched under torchrun; no-op for a single process."""
+    """Join the process group when launched under torchrun; no-op for a single process.
+    Rehearsal switches for a one-GPU box (never needed on a real node): ``LSM_DIST_BACKEND=gloo`` exchanges
+    through the host, ``LSM_SHARE_GPU=1`` puts every rank on cuda:0."""
     rank, local_rank, world = env_world()
+    if os.environ.get("LSM_SHARE_GPU") == "1":
+        local_rank = 0
     if world > 1 and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         if backend is None:
-            backend = "nccl" if torch.cuda.is_available() else "gloo"
+            backend = os.environ.get("LSM_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         if backend == "nccl":
             torch.cuda.set_device(local_rank)
             dist.init_process_group(backend, device_id=torch.device("cuda", local_rank))
         else:
+            if torch.cuda.is_available():
+                torch.cuda.set_device(local_rank)
             dist.init_process_group(backend)
     return rank, local_rank, world
+
+
+def local_device() -> torch.device:
+    """The GPU of this rank (LOCAL_RANK; cuda:0 for a single process or under LSM_SHARE_GPU=1)."""
+    _, local_rank, world = env_world()
+    if world <= 1 or os.environ.get("LSM_SHARE_GPU") == "1":
+        local_rank = 0 if world > 1 else (torch.cuda.current_device() if torch.cuda.is_available() else 0)
+    return torch.device("cuda", local_rank)
 
 
 def group_world():
@@ -78,6 +92,27 @@ def gather_rows(local: torch.Tensor, n_total: int) -> torch.Tensor:
     out = torch.empty((world * per, local.shape[1]), dtype=local.dtype, device=local.device)
     dist.all_gather_into_tensor(out, pad)
     return out[:n_total]
+
+
+def gather_varrows(local: torch.Tensor) -> torch.Tensor:
+    """All-gather row blocks whose lengths the ranks do not know of each other (stage 1: a rank skips the wav
+    files it cannot read), in rank order.  ``local`` is (n_r, F) on this rank's device, F equal on every rank;
+    every rank returns (sum n_r, F).  Two collectives: the counts, then the blocks padded to the longest."""
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return local
+    world = dist.get_world_size()
+    counts = torch.zeros((world,), dtype=torch.int64, device=local.device)
+    mine = torch.tensor([local.shape[0]], dtype=torch.int64, device=local.device)
+    dist.all_gather_into_tensor(counts, mine)
+    counts = [int(c) for c in counts.cpu()]
+    per = max(counts) if counts else 0
+    if per == 0:
+        return local[:0]
+    pad = torch.zeros((per, local.shape[1]), dtype=local.dtype, device=local.device)
+    pad[: local.shape[0]] = local
+    out = torch.empty((world * per, local.shape[1]), dtype=local.dtype, device=local.device)
+    dist.all_gather_into_tensor(out, pad)
+    return torch.cat([out[r * per: r * per + counts[r]] for r in range(world)])
 
 
 def broadcast_float(value: float, src: int = 0, device=None) -> float:

@@ -7,6 +7,7 @@ pointers; all per-sample arithmetic runs in liblsm_hip.so.  No CPU fallback exis
 from __future__ import annotations
 
 import ctypes as C
+import os
 
 import numpy as np
 import torch
@@ -95,8 +96,8 @@ def threshold_tables(thresholds, gap: float, dtype):
     return on, off
 
 
-def _stream() -> int:
-    return torch.cuda.current_stream().cuda_stream
+def _stream(device=None) -> int:
+    return torch.cuda.current_stream(device).cuda_stream
 
 
 def _dev(t: torch.Tensor) -> C.c_void_p:
@@ -118,6 +119,8 @@ class SpikeFrontEnd:
             raise ValueError(f"filterbank must be 'mel' or 'gammatone', got {filterbank!r}")
         self.lib = _lib.load()
         self.device = torch.device(device if device is not None else "cuda")
+        if self.device.type == "cuda" and self.device.index is None:      # pin the device NOW: later calls may
+            self.device = torch.device("cuda", torch.cuda.current_device())   # come under another current device
         self.n_filters = int(n_filters)
         self.filterbank = filterbank
         self.redundancy = int(redundancy)
@@ -147,6 +150,13 @@ class SpikeFrontEnd:
     def n_steps(self) -> int:
         return self.time_bins * len(self.thresholds)
 
+    def _stream(self) -> int:
+        """The current stream of THIS front end's device (not of whatever device is current)."""
+        return torch.cuda.current_stream(self.device).cuda_stream
+
+    def _indexed_device(self) -> torch.device:
+        return self.device
+
     def _audio(self, audio) -> torch.Tensor:
         if isinstance(audio, np.ndarray):
             audio = torch.from_numpy(np.ascontiguousarray(audio, dtype=np.float32))
@@ -163,13 +173,15 @@ class SpikeFrontEnd:
         audio = self._audio(audio)
         B = audio.shape[0]
         if self.filterbank == "mel":
-            return self._mel.power_db(audio), None
-        db = torch.empty((B, self.n_filters, self.ncols), dtype=torch.float64, device=self.device)
-        spec = torch.empty_like(db) if want_spec else None
-        _lib.check(self.lib.lsm_gammatone_spec_f64(
-            _dev(audio), B, self.n_samples, _dev(self.coefs), self.n_filters, self.nwin, self.hop,
-            self.ncols, _dev(spec) if want_spec else None, _dev(db), self.coef_flags, _stream()),
-            "lsm_gammatone_spec_f64")
+            with torch.cuda.device(self.device):
+                return self._mel.power_db(audio), None
+        with torch.cuda.device(self.device):       # launch on THIS device's current stream
+            db = torch.empty((B, self.n_filters, self.ncols), dtype=torch.float64, device=self.device)
+            spec = torch.empty_like(db) if want_spec else None
+            _lib.check(self.lib.lsm_gammatone_spec_f64(
+                _dev(audio), B, self.n_samples, _dev(self.coefs), self.n_filters, self.nwin, self.hop,
+                self.ncols, _dev(spec) if want_spec else None, _dev(db), self.coef_flags, self._stream()),
+                "lsm_gammatone_spec_f64")
         return db, spec
 
     def spikes_from_db(self, db: torch.Tensor, want_norm: bool = False, want_raster: bool = True):
@@ -178,21 +190,46 @@ class SpikeFrontEnd:
         f64 = db.dtype == torch.float64
         np_dt = np.float64 if f64 else np.float32
         on, off = threshold_tables(self.thresholds, self.gap, np_dt)
-        raster = (torch.empty((B, self.n_channels, self.n_steps), dtype=torch.uint8, device=self.device)
-                  if want_raster else None)
-        norm = (torch.empty((B, self.n_filters, self.time_bins), dtype=db.dtype, device=self.device)
-                if want_norm else None)
-        fn = self.lib.lsm_spec_to_spikes_f64 if f64 else self.lib.lsm_spec_to_spikes_f32
-        _lib.check(fn(_dev(db), B, self.n_filters, db.shape[2], self.time_bins,
-                      1 if self.filterbank == "gammatone" else 0, _host(on), _host(off), len(on),
-                      self.redundancy, _dev(raster) if want_raster else None,
-                      _dev(norm) if want_norm else None, _stream()), "lsm_spec_to_spikes")
+        if db.device != self._indexed_device():
+            raise ValueError(f"spectrogram on {db.device}, front end on {self.device}")
+        db = db.contiguous()
+        with torch.cuda.device(self.device):
+            raster = (torch.empty((B, self.n_channels, self.n_steps), dtype=torch.uint8, device=self.device)
+                      if want_raster else None)
+            norm = (torch.empty((B, self.n_filters, self.time_bins), dtype=db.dtype, device=self.device)
+                    if want_norm else None)
+            fn = self.lib.lsm_spec_to_spikes_f64 if f64 else self.lib.lsm_spec_to_spikes_f32
+            _lib.check(fn(_dev(db), B, self.n_filters, db.shape[2], self.time_bins,
+                          1 if self.filterbank == "gammatone" else 0, _host(on), _host(off), len(on),
+                          self.redundancy, _dev(raster) if want_raster else None,
+                          _dev(norm) if want_norm else None, self._stream()), "lsm_spec_to_spikes")
         return raster, norm
 
-    def encode(self, audio) -> torch.Tensor:
-        """audio (B, n_samples) -> uint8 spike raster (B, C, n_steps) on the device."""
-        db, _ = self.spectrogram_db(audio)
-        raster, _ = self.spikes_from_db(db)
+    def encode(self, audio, fused: bool | None = None) -> torch.Tensor:
+        """audio (B, n_samples) -> uint8 spike raster (B, C, n_steps) on the device.  The gammatone branch
+        is one launch (`lsm_gammatone_spikes_f64`); `fused=False` takes the two split entry points
+        (identical rasters), which is also what the mel branch and > 1024 filters use."""
+        if fused is None:
+            # LSM_FRONTEND_SPLIT=1: diagnostic switch for same-box A/B runs of the two routes (exp/r03_fused_sweep.sh)
+            fused = (self.filterbank == "gammatone" and self.n_filters <= 1024
+                     and os.environ.get("LSM_FRONTEND_SPLIT") != "1")
+        if not fused:
+            db, _ = self.spectrogram_db(audio)
+            raster, _ = self.spikes_from_db(db)
+            return raster
+        if self.filterbank != "gammatone":
+            raise ValueError("the fused front end is the gammatone branch")
+        audio = self._audio(audio)
+        B = audio.shape[0]
+        on, off = threshold_tables(self.thresholds, self.gap, np.float64)
+        with torch.cuda.device(self.device):
+            raster = torch.empty((B, self.n_channels, self.n_steps), dtype=torch.uint8, device=self.device)
+            ws_bytes = int(self.lib.lsm_gammatone_spikes_workspace(B, self.n_filters, self.ncols))
+            ws = torch.empty((max(ws_bytes, 8) // 8,), dtype=torch.float64, device=self.device)
+            _lib.check(self.lib.lsm_gammatone_spikes_f64(
+                _dev(audio), B, self.n_samples, _dev(self.coefs), self.n_filters, self.nwin, self.hop,
+                self.ncols, self.time_bins, _host(on), _host(off), len(on), self.redundancy, _dev(raster),
+                _dev(ws), ws_bytes, self.coef_flags, self._stream()), "lsm_gammatone_spikes_f64")
         return raster
 
 

@@ -76,7 +76,7 @@ class MelSpectrogram:
         _lib.check(self.lib.lsm_mel_power_f32(
             p(audio), B, self.n_samples, N_FFT, self.hop, self.n_frames, p(self.window),
             p(self.twiddle), p(self.basis), p(self.lo), p(self.hi), self.n_mels, p(out),
-            torch.cuda.current_stream().cuda_stream), "lsm_mel_power_f32")
+            torch.cuda.current_stream(self.device).cuda_stream), "lsm_mel_power_f32")
         return out
 
     def power_db(self, audio: torch.Tensor) -> torch.Tensor:
@@ -85,6 +85,6 @@ class MelSpectrogram:
         out = torch.empty_like(S)
         _lib.check(self.lib.lsm_power_to_db_f32(
             C.c_void_p(S.data_ptr()), S.shape[0], S.shape[1] * S.shape[2], C.c_float(AMIN),
-            C.c_float(TOP_DB), C.c_void_p(out.data_ptr()), torch.cuda.current_stream().cuda_stream),
+            C.c_float(TOP_DB), C.c_void_p(out.data_ptr()), torch.cuda.current_stream(self.device).cuda_stream),
             "lsm_power_to_db_f32")
         return out

@@ -3,11 +3,11 @@
 The reference chains its stages through files and serial Python loops
 (/root/reference/main.py:19-27; clip loops at create_dataset.py:143 and extract_lsm_features.py:78).
 Here one STEP = one batch of clips through filterbank -> dB/normalise/resize -> hysteresis encoder ->
-LIF reservoir -> features, all on the GPU, and consecutive steps are issued on rotating HIP streams: the
+LIF reservoir -> features, all on the GPU -- two launches since round 3, the fused front end
+(`lsm_gammatone_spikes_f64`) and the reservoir -- and consecutive steps are issued on rotating HIP streams: the
 work of a step is ordered on its own stream, the float64 filterbank of step s+1 runs beside the
 latency-bound reservoir kernel of step s and refills the CUs that clips finishing early leave idle.
-Every step still does all its work; per-step latency grows, throughput rises (measured at 128 filters /
-1000 neurons / 256 clips: 132 k clips/s on one stream, 356 k on six).
+Every step still does all its work; per-step latency grows, throughput rises.
 
 `HotPath` owns what used to live in bench.py: the stream rotation, the layout hint for the reservoir
 kernel (a launch that shares the chip with other kernels prefers fewer, fatter waves than a lone one:
@@ -22,25 +22,19 @@ import torch
 
 DEFAULT_STREAMS = 6
 DEFAULT_HW_QUEUES = 12
+STAGES = ("full", "frontend", "reservoir")
 
 
 def configure_hardware_queues(n: int = DEFAULT_HW_QUEUES) -> int:
     """The HIP runtime multiplexes streams onto 4 hardware queues by default, and kernels of streams that
     share a queue serialise: with 4 queues three streams are the optimum, with 8-12 six streams overlap
     (0.96 -> 0.72 ms per step; 12 also leave RCCL's stream a queue of its own).  The variable is read when
-    HIP initialises, so this must run BEFORE the first CUDA/HIP call of the process; importing this
-    module does it (an existing GPU_MAX_HW_QUEUES wins).  Returns the value in force."""
-    if "GPU_MAX_HW_QUEUES" not in os.environ:
-        if torch.cuda.is_initialized():
-            import warnings
-            warnings.warn("HIP is already initialised: GPU_MAX_HW_QUEUES cannot be raised any more, "
-                          "overlapping streams will share 4 hardware queues", RuntimeWarning)
-        else:
-            os.environ["GPU_MAX_HW_QUEUES"] = str(int(n))
-    return int(os.environ.get("GPU_MAX_HW_QUEUES", "4"))
-
-
-configure_hardware_queues()
+    HIP initialises, so it must be set BEFORE the first CUDA/HIP call of the process: importing the package
+    does that (`lsm_speech_classifier_amd.__init__`, an existing GPU_MAX_HW_QUEUES wins; a warning when HIP
+    was already up).  Returns the number of queues IN FORCE for this process, which is what `HotPath.hw_queues`
+    and the bench line report -- 4 when the package was imported too late, whatever the variable says now."""
+    from . import EFFECTIVE_HW_QUEUES
+    return int(EFFECTIVE_HW_QUEUES)
 
 
 class HotPath:
@@ -62,7 +56,7 @@ class HotPath:
         # inside the rotation the reservoir launch shares the chip: let the library pick for that case
         self.waves_per_clip = (-1 if self.n_streams > 1 else 0) if waves_per_clip is None else int(waves_per_clip)
         self.time_reservoir = bool(time_reservoir)
-        self.hw_queues = int(os.environ.get("GPU_MAX_HW_QUEUES", "4"))
+        self.hw_queues = configure_hardware_queues()
         with torch.cuda.device(self.device):
             self.streams = ([torch.cuda.Stream(device=self.device) for _ in range(self.n_streams)]
                             if self.n_streams > 1 else [None])
@@ -71,32 +65,53 @@ class HotPath:
         self._h2d = {}
 
     # ---- one step ---------------------------------------------------------------------------
-    def _one(self, audio, stats_out):
-        rasters = self.fe.encode(audio)
+    def _one(self, x, stats_out, out, stage):
+        if stage == "frontend":
+            return self.fe.encode(x)
+        rasters = x if stage == "reservoir" else self.fe.encode(x)
         if self.time_reservoir:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
         feats, _, _ = self.net.run_batch(rasters, self.feature_keys, waves_per_clip=self.waves_per_clip,
-                                         stats_out=stats_out)
+                                         stats_out=stats_out, features_out=out)
         if self.time_reservoir:
             e1.record()
             self.reservoir_events.append((e0, e1))
         return feats
 
-    def submit(self, audio, stats_out=None, after=None):
-        """Issue one step for `audio` ((B, n_samples) float32: device tensor, or pinned/pageable host
-        tensor / NumPy array, uploaded on the step's own stream) on the next stream of the rotation.
-        Returns (features (B, n_keys*N_out) device tensor, stream it is produced on).  The caller waits
-        (`stream.synchronize()`, `HotPath.synchronize()`, or an event) before reading the features."""
-        st = self.streams[self._step % self.n_streams]
+    def submit(self, audio, stats_out=None, after=None, out=None, stage: str = "full"):
+        """Issue one step on the next stream of the rotation.  `audio`: (B, n_samples) float32 -- device tensor,
+        or pinned/pageable host tensor / NumPy array, uploaded on the step's own stream.  Returns (features
+        (B, n_keys*N_out) device tensor, stream it is produced on); the caller waits (`stream.synchronize()`,
+        `HotPath.synchronize()`, or an event) before reading the features.
+
+        Ordering of a DEVICE input: the step's stream waits for `after` when that event is given, otherwise for
+        everything the current stream of the device has issued so far (so a batch produced there just before
+        `submit()` is never read early); host inputs are copied on the step's stream itself.
+        `out`: write the rows into this (B, n_feat) float32 tensor (a slice of a gather buffer) instead of a new one.
+        `stage`: "full"; "frontend" (returns the uint8 rasters; `out`/`stats_out` unused); "reservoir" (`audio` IS a
+        uint8 raster batch (B, C, T) on the device) -- the same rotation, launches and layout hint as a full step,
+        so that per-stage timings go through the code the headline goes through."""
+        if stage not in STAGES:
+            raise ValueError(f"stage must be one of {STAGES}, got {stage!r}")
         slot = self._step % self.n_streams
+        st = self.streams[slot]
         self._step += 1
+        cur = torch.cuda.current_stream(self.device)
+        on_device = torch.is_tensor(audio) and audio.device == self.device
         if st is None:
-            return self._one(self._to_device(audio, slot), stats_out), torch.cuda.current_stream(self.device)
-        with torch.cuda.stream(st):
+            if after is not None:
+                cur.wait_event(after)
+            with torch.cuda.device(self.device):
+                x = audio if stage == "reservoir" else self._to_device(audio, slot)
+                return self._one(x, stats_out, out, stage), cur
+        with torch.cuda.device(self.device), torch.cuda.stream(st):
             if after is not None:
                 st.wait_event(after)
-            return self._one(self._to_device(audio, slot), stats_out), st
+            elif on_device:
+                st.wait_stream(cur)
+            x = audio if stage == "reservoir" else self._to_device(audio, slot)
+            return self._one(x, stats_out, out, stage), st
 
     def _to_device(self, audio, slot):
         if isinstance(audio, np.ndarray):
@@ -111,7 +126,7 @@ class HotPath:
         buf.copy_(audio, non_blocking=True)
         return buf
 
-    def prime(self, audio):
+    def prime(self, audio, stage: str = "full"):
         """One untimed step on EVERY stream of the rotation, then a synchronisation: each stream's first use
         pays for its allocator pool (torch caches device memory per stream: the first `encode` on a stream
         calls hipMalloc, which stalls every queue), for the first launch on its hardware queue and for the
@@ -121,7 +136,7 @@ class HotPath:
         events = self.reservoir_events
         self.reservoir_events = []
         for _ in range(self.n_streams):
-            self.submit(audio)
+            self.submit(audio, stage=stage)
         self.synchronize()
         self.reservoir_events = events
 
@@ -132,6 +147,14 @@ class HotPath:
         for st in self.streams:
             if st is not None:
                 st.wait_stream(cur)
+
+    def join_to_current(self):
+        """The reverse edge: the current stream waits for everything the rotation has issued (no host
+        synchronisation) -- e.g. before ONE collective over the rows of many steps."""
+        cur = torch.cuda.current_stream(self.device)
+        for st in self.streams:
+            if st is not None:
+                cur.wait_stream(st)
 
     def synchronize(self):
         for st in self.streams:
@@ -156,15 +179,18 @@ class HotPath:
 
 
 def features_from_audio(audio: np.ndarray, fe, net, feature_keys, batch: int = 1024,
-                        streams: int = DEFAULT_STREAMS) -> np.ndarray:
+                        streams: int = DEFAULT_STREAMS, device_out: bool = False):
     """Host convenience for the drop-in scripts' in-memory path: (n, n_samples) float32 on the host ->
-    (n, n_feat) float32 on the host, batches of `batch` clips through the overlapped pipeline (pinned
-    staging, uploads on the steps' streams)."""
+    (n, n_feat) float32 on the host (or, `device_out`, still on the GPU for a gather), batches of `batch` clips
+    through the overlapped pipeline (pinned staging, uploads on the steps' streams).  n = 0 (an empty shard)
+    gives an empty (0, n_feat) block."""
     hp = HotPath(fe, net, feature_keys, streams=streams)
     pinned = torch.from_numpy(np.ascontiguousarray(audio, dtype=np.float32))
-    try:
-        pinned = pinned.pin_memory()
-    except RuntimeError:
-        pass
-    feats = hp.run(pinned[lo:lo + batch] for lo in range(0, len(pinned), batch))
-    return feats.cpu().numpy()
+    if len(pinned):
+        try:
+            pinned = pinned.pin_memory()
+        except RuntimeError:
+            pass
+    with torch.cuda.device(hp.device):
+        feats = hp.run(pinned[lo:lo + batch] for lo in range(0, len(pinned), batch))
+    return feats if device_out else feats.cpu().numpy()

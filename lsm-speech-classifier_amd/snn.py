@@ -39,6 +39,8 @@ class SNN:
         self.lib = _lib.load()
         self.params = simulation_params
         self.device = torch.device(device if device is not None else "cuda")
+        if self.device.type == "cuda" and self.device.index is None:        # pin it now (as frontend.SpikeFrontEnd)
+            self.device = torch.device("cuda", torch.cuda.current_device())
         if reservoir is None:
             if n_channels is None:
                 ist = simulation_params.input_spike_times
@@ -74,7 +76,7 @@ class SNN:
 
     # ---- batched path -------------------------------------------------------------------
     def run_batch(self, spikes, feature_keys=None, want_spike_matrix=False, want_v_trace=False,
-                  waves_per_clip: int = 0, packed_time_steps: int = 0, stats_out=None):
+                  waves_per_clip: int = 0, packed_time_steps: int = 0, stats_out=None, features_out=None):
         """spikes: uint8 (B, C, T) torch tensor on this device (or NumPy, copied).  Returns
         (features float32 (B, n_keys*N_out) device tensor, spike_matrix or None, v_trace or None);
         NaN entries are already 0 and keys are concatenated in the given order
@@ -83,7 +85,9 @@ class SNN:
         ``stats_out``: optional int32 (B, 2) device tensor that receives, per clip, the number of neurons
         that fired at least once and the spikes of the whole reservoir (accumulated inside the kernel).
         ``waves_per_clip``: 0 = the library's layout for a lone launch, -1 = its layout for a launch that
-        shares the GPU with other kernels (``pipeline.HotPath``), else 1, 2, 4, 8 or 16."""
+        shares the GPU with other kernels (``pipeline.HotPath``), else 1, 2, 4, 8 or 16.
+        ``features_out``: optional contiguous float32 (B, n_keys*N_out) device tensor to write the rows into
+        (e.g. this step's slice of a gather buffer) instead of a fresh one."""
         if isinstance(spikes, np.ndarray):
             spikes = torch.from_numpy(np.ascontiguousarray(spikes, dtype=np.uint8))
         spikes = spikes.to(self.device, dtype=torch.uint8).contiguous()
@@ -96,8 +100,15 @@ class SNN:
         B, _, T = spikes.shape
         keys = FEATURE_KEYS if feature_keys is None else [k for k in feature_keys if k in FEATURE_KEYS]
         key_ids = np.array([FEATURE_KEYS.index(k) for k in keys], dtype=np.int32)
-        feats = torch.empty((B, len(keys) * self.num_output_neurons), dtype=torch.float32,
-                            device=self.device)
+        if features_out is not None:
+            if (features_out.dtype != torch.float32 or tuple(features_out.shape) != (B, len(keys) * self.num_output_neurons)
+                    or not features_out.is_contiguous() or features_out.device != spikes.device):
+                raise ValueError(f"features_out must be a contiguous float32 ({B}, {len(keys) * self.num_output_neurons}) "
+                                 f"tensor on {spikes.device}")
+            feats = features_out
+        else:
+            feats = torch.empty((B, len(keys) * self.num_output_neurons), dtype=torch.float32,
+                                device=self.device)
         sm = (torch.empty((B, T, self.num_neurons), dtype=torch.uint8, device=self.device)
               if want_spike_matrix else None)
         vt = (torch.empty((B, T, self.num_neurons), dtype=torch.float32, device=self.device)
@@ -108,7 +119,7 @@ class SNN:
         with torch.cuda.device(self.device):
             _lib.check(self.lib.lsm_reservoir_run(
                 self._handle, _dev(spikes), B, T, _host(key_ids), len(keys), _dev(feats), _dev(sm),
-                _dev(vt), _dev(stats_out), int(waves_per_clip), torch.cuda.current_stream().cuda_stream),
+                _dev(vt), _dev(stats_out), int(waves_per_clip), torch.cuda.current_stream(self.device).cuda_stream),
                 "lsm_reservoir_run")
         return feats, sm, vt
 
@@ -133,6 +144,10 @@ class SNN:
     KERNEL_MODES = {"auto": 0, "sparse": 1, "dense": 2, "ring": 3, "band": 3, "ring-contiguous": 4}
 
     def set_kernel(self, mode: str = "auto"):
+        with torch.cuda.device(self.device):
+            return self._set_kernel(mode)
+
+    def _set_kernel(self, mode: str = "auto"):
         """'auto' (register accumulation over dense presynaptic rows; over ring rows -- dense ring window
         plus a list of the rewired synapses -- for ring-like reservoirs whose dense table exceeds the L2
         caches), 'sparse' (CSC scatter through LDS), 'dense' or 'ring'."""
@@ -141,6 +156,16 @@ class SNN:
 
     def kernel_in_use(self) -> str:
         return {1: "sparse", 2: "dense", 3: "ring"}[self.lib.lsm_reservoir_kernel_in_use(self._handle)]
+
+    def plan(self, n_clips: int, n_steps: int, waves_per_clip: int = 0) -> dict:
+        """What `run_batch` would launch for this batch: kernel, layout, LDS bytes per clip and the bytes of the
+        weight table that kernel gathers from (`lsm_reservoir_plan`)."""
+        k, wpc, sl, lds, tab = C.c_int(), C.c_int(), C.c_int(), C.c_int(), C.c_long()
+        _lib.check(self.lib.lsm_reservoir_plan(self._handle, n_clips, n_steps, waves_per_clip, C.byref(k),
+                                               C.byref(wpc), C.byref(sl), C.byref(lds), C.byref(tab)),
+                   "lsm_reservoir_plan")
+        return {"kernel": {1: "sparse", 2: "dense", 3: "ring"}[k.value], "waves_per_clip": wpc.value,
+                "slots_per_lane": sl.value, "lds_bytes": lds.value, "table_bytes": tab.value}
 
     def layout(self, n_clips: int, n_steps: int, waves_per_clip: int = 0):
         wpc, sl, lds = C.c_int(), C.c_int(), C.c_int()

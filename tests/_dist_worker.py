@@ -42,7 +42,13 @@ def main():
         feats = ex.extract_all_features(FakeLsm(), clips, ["a", "b"], "")
     lo, hi = lsm_dist.shard_range(n, rank, world)
     w = lsm_dist.broadcast_float(3.25 + rank, 0)
-    np.savez(os.path.join(out_dir, f"rank{rank}.npz"), feats=feats, lo=lo, hi=hi, w=w)
+    # stage 1's exchange: blocks whose lengths the ranks do not know of each other (rank 1 contributes nothing)
+    n_mine = 0 if rank == 1 else 2 * rank + 3
+    block = (torch.arange(n_mine * 5, dtype=torch.int32).reshape(n_mine, 5) + 1000 * rank).to(torch.uint8 if gpu else torch.int32)
+    if gpu:
+        block = block.cuda()
+    var = lsm_dist.gather_varrows(block).cpu().numpy()
+    np.savez(os.path.join(out_dir, f"rank{rank}.npz"), feats=feats, lo=lo, hi=hi, w=w, var=var)
     torch.distributed.barrier()
     torch.distributed.destroy_process_group()
 

@@ -32,3 +32,16 @@ def test_bench_launcher_sets_its_own_rendezvous_and_rejects_bad_flags():
     bad = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--config", "nope"],
                          capture_output=True, text=True, timeout=120)
     assert bad.returncode != 0                                     # argparse error in the parent itself
+
+
+def test_a_rank_that_dies_before_the_rendezvous_ends_the_run_promptly():
+    """rank 1 exits 3 before init_process_group while ranks 0 and 2 wait in the rendezvous; the parent
+    polls its children, terminates the survivors and returns that status -- within seconds, not after the
+    process-group timeout (minutes)."""
+    import time
+    t0 = time.time()
+    p = _run(3, {"LSM_BENCH_SPAWN_DIE": "1:3"})
+    took = time.time() - t0
+    assert p.returncode == 3, (p.returncode, p.stderr[-2000:])
+    assert took < 90, took
+    assert not [ln for ln in p.stdout.splitlines() if ln.startswith("{")]      # nobody reported a result

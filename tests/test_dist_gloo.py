@@ -43,4 +43,7 @@ def test_sharded_feature_gather_equals_single_process(tmp_path, world, n):
         np.testing.assert_array_equal(d["feats"], single)          # all rows, dataset order, every rank
         covered += list(range(int(d["lo"]), int(d["hi"])))
         assert float(d["w"]) == 3.25                                # rank 0's value everywhere
+        want = np.concatenate([np.arange((0 if r == 1 else 2 * r + 3) * 5, dtype=np.int32).reshape(-1, 5) + 1000 * r
+                               for r in range(world)])
+        np.testing.assert_array_equal(d["var"], want)               # ragged blocks, rank order, every rank
     assert covered == list(range(n))

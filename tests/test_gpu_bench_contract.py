@@ -34,9 +34,24 @@ def test_bench_line_contract():
         assert key in r, key
     assert r["bound"] == "hbm" and r["peak"] == 8000.0 and r["unit"] == "GB/s"
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-4 and r["kernel_ms"] > 0
+    # the line says where `traffic` comes from (never a silent null), and carries the gather ceiling
+    assert r["traffic"] is None and r["traffic_source"].startswith("none:") and "cfg2_B64_dense" in r["traffic_source"]
+    assert r["gather_ceiling"] == 16800.0 and 4e6 < r["weight_table_bytes"] < 4.5e6      # 1000 x 1024 x 4: L2 resident
+    g = r["row_gather"]
+    assert g["rows_per_launch"] > 0 and 0 < g["frac_of_gather_ceiling"] < 1 and g["mean_row_bytes"] == 4096.0
+    assert r["memory_side_frac"] is None
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["cores"] == 1 and c["unit"] == "clips/s" and c["value"] > 0 and c["sample"]
     assert d["value"] / c["value"] > 100           # north star: >= 100x the CPU reference at 1 GPU
+
+
+def test_bench_line_names_the_committed_traffic_file_at_the_headline_shape():
+    d = _run("--no-cpu-baseline")                       # cfg2 at its own batch: the shape profiles/lif_traffic.json holds
+    r = d["roofline"]
+    assert r["traffic"] > 0 and "profiles/lif_traffic.json[cfg2_B256_dense]" in r["traffic_source"]
+    assert "not measured in this run" in r["traffic_source"]
+    assert 0 < r["memory_side_frac"] < 1 and r["memory_side_gbs_lone_launch"] > 0
+    assert d["config"]["hw_queues"] == 12 and d["config"]["streams"] == 6
 
 
 def test_bench_stages_and_serial_mode():

@@ -1,0 +1,116 @@
+"""The one-launch gammatone front end (`lsm_gammatone_spikes_f64`: filterbank -> dB -> floor/normalise -> resize
+-> hysteresis encoder) against the C oracle, the reference-generated golden fixtures' semantics and the two split
+entry points.  Reference: /root/reference/create_dataset.py:49-104 (per-clip body of the loop at :143-157)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+THR = [0.70, 0.80, 0.90, 0.95]
+GAP = 0.1
+
+
+@pytest.fixture(scope="module")
+def torch_cuda():
+    import torch
+    assert torch.cuda.is_available(), "GPU tests need a HIP device"
+    from lsm_speech_classifier_amd import _lib
+    _lib.require_gpu()
+    return torch
+
+
+def _oracle_raster(oracle_c, audio, n_filters, nwin=400, hop=160, ncols=98, thr=THR, gap=GAP, time_bins=100):
+    from oracle import ref_numpy as O
+    coefs = O.gammatone_coefs(16000, n_filters, 50)
+    out = []
+    for a in audio:
+        spec = oracle_c.gammatone_spec(a, coefs, nwin, hop, ncols)
+        out.append(oracle_c.encode_hysteresis(oracle_c.normalise_resize(oracle_c.gammatone_db(spec), time_bins),
+                                              thr, gap))
+    return np.stack(out)
+
+
+@pytest.mark.parametrize("n_filters", [2, 40, 64, 65, 128, 200, 256])
+def test_fused_front_end_matches_oracle_and_split_path(torch_cuda, oracle_c, n_filters):
+    """One and two chains per lane, one / two waves per clip, ragged last channel group, silent and flat clips,
+    a batch that does not fill its last workgroup."""
+    from lsm_speech_classifier_amd import frontend, synth
+    audio = np.concatenate([synth.class_chirps([0, 3, 7, 11, 5], seed=21), synth.white_noise(3, seed=5)])
+    audio[2] = 0.0                                            # silent clip: flat spectrogram -> zeros (:64-65)
+    audio[6] = 0.25                                           # constant clip
+    fe = frontend.SpikeFrontEnd(n_filters, "gammatone")
+    fused = fe.encode(audio, fused=True)
+    split = fe.encode(audio, fused=False)
+    assert fused.shape == (len(audio), n_filters, 400) and fused.dtype == torch_cuda.uint8
+    assert torch_cuda.equal(fused, split)
+    got = fused.cpu().numpy()
+    assert not got[2].any()
+    np.testing.assert_array_equal(got, _oracle_raster(oracle_c, audio, n_filters))
+    assert got.sum() > 0
+
+
+def test_fused_redundancy_and_other_threshold_tables(torch_cuda, oracle_c):
+    from lsm_speech_classifier_amd import frontend, synth
+    audio = synth.class_chirps([1, 4, 9], seed=3)
+    for red, thr, gap in ((3, THR, GAP), (2, [0.5], 0.05), (1, [0.3, 0.6, 0.65, 0.7, 0.8, 0.9, 0.95, 0.99], 0.02)):
+        fe = frontend.SpikeFrontEnd(96, "gammatone", redundancy=red, thresholds=thr, gap=gap)
+        got = fe.encode(audio, fused=True)
+        assert torch_cuda.equal(got, fe.encode(audio, fused=False))
+        ref = np.repeat(_oracle_raster(oracle_c, audio, 96, thr=thr, gap=gap), red, axis=1)
+        np.testing.assert_array_equal(got.cpu().numpy(), ref)
+
+
+@pytest.mark.parametrize("n_samples,time_bins", [(12000, 100), (16000, 100), (24000, 100), (48000, 100), (13000, 100),
+                                                 (8000, 50), (12345, 77), (16000, 98), (16000, 40)])
+def test_fused_other_clip_lengths_and_window_overlaps(torch_cuda, oracle_c, n_samples, time_bins):
+    """1-4 overlapping windows, hops that are not multiples of 8, a column count equal to the bin count (no
+    resize) -- the cases of test_gpu_fuzz.py's split-path test, through the fused entry point."""
+    from lsm_speech_classifier_amd import frontend, synth
+    rng = np.random.RandomState(n_samples + time_bins)
+    base = synth.class_chirps([2, 6, 10], seed=8)
+    audio = np.ascontiguousarray(np.resize(base, (3, n_samples)).astype(np.float32))
+    audio += 0.01 * rng.randn(3, n_samples).astype(np.float32)
+    fe = frontend.SpikeFrontEnd(72, "gammatone", n_samples=n_samples, time_bins=time_bins)
+    assert 1 <= (fe.nwin + fe.hop - 1) // fe.hop <= 4
+    got = fe.encode(audio, fused=True)
+    assert torch_cuda.equal(got, fe.encode(audio, fused=False))
+    ref = _oracle_raster(oracle_c, audio, 72, nwin=fe.nwin, hop=fe.hop, ncols=fe.ncols, time_bins=time_bins)
+    np.testing.assert_array_equal(got.cpu().numpy(), ref)
+
+
+def test_fused_large_batch_equals_small_batches_and_split_path(torch_cuda):
+    """cfg2's launch shape (256 clips x 128 filters: one wave per clip, CU-exclusive placement) and a launch
+    that needs several workgroups per CU; batch position must not matter."""
+    from lsm_speech_classifier_amd import frontend, synth
+    audio = synth.class_chirps(np.arange(1100) % 12, seed=77)
+    fe = frontend.SpikeFrontEnd(128, "gammatone")
+    dev = torch_cuda.from_numpy(audio).cuda()
+    big = fe.encode(dev, fused=True)
+    assert torch_cuda.equal(big, fe.encode(dev, fused=False))
+    assert torch_cuda.equal(big[:256], fe.encode(dev[:256], fused=True))
+    assert torch_cuda.equal(big[1000:1003], fe.encode(dev[1000:1003], fused=True))
+
+
+def test_fused_argument_errors(torch_cuda):
+    import ctypes as C
+    from lsm_speech_classifier_amd import _lib, frontend
+    lib = _lib.load()
+    fe = frontend.SpikeFrontEnd(128, "gammatone")
+    audio = torch_cuda.zeros((4, 16000), dtype=torch_cuda.float32, device="cuda")
+    raster = torch_cuda.empty((4, 128, 400), dtype=torch_cuda.uint8, device="cuda")
+    need = lib.lsm_gammatone_spikes_workspace(4, 128, 98)
+    assert need == 4 * 98 * 128 * 8
+    ws = torch_cuda.empty((need // 8,), dtype=torch_cuda.float64, device="cuda")
+    on, off = frontend.threshold_tables(THR, GAP, np.float64)
+    p = lambda t: C.c_void_p(t.data_ptr())
+    h = lambda a: C.c_void_p(a.ctypes.data)
+    call = lambda **kw: lib.lsm_gammatone_spikes_f64(
+        p(audio), kw.get("B", 4), 16000, p(fe.coefs), 128, 400, 160, 98, 100, h(on), h(off), kw.get("n_thr", 4),
+        kw.get("red", 1), kw.get("raster", p(raster)), p(ws), kw.get("ws_bytes", need), fe.coef_flags, None)
+    assert call() == 0
+    assert call(B=0) == 0
+    assert call(ws_bytes=need - 8) == -1 and b"workspace" in lib.lsm_last_error()
+    assert call(n_thr=9) == -1
+    assert call(red=0) == -1
+    assert call(raster=None) == -1
+    torch_cuda.cuda.synchronize()

@@ -18,7 +18,7 @@ def test_library_exports_every_declared_symbol():
     if not os.path.exists(build.lib_path()):
         build.build()
     header = open(os.path.join(ROOT, "include", "lsm_hip.h")).read()
-    declared = set(re.findall(r"^\s*(?:const\s+char\s*\*|int)\s*\*?\s*(lsm_[a-z0-9_]+)\s*\(", header, re.M))
+    declared = set(re.findall(r"^\s*(?:const\s+char\s*\*|int|long)\s*\*?\s*(lsm_[a-z0-9_]+)\s*\(", header, re.M))
     assert len(declared) >= 12
     lib = _lib.load()
     for name in declared:
@@ -159,7 +159,11 @@ def test_script_surface_matches_the_reference(golden_dir):
         assert callable(fn)
     import inspect
     assert list(inspect.signature(cd.create_dataset).parameters)[:2] == ["n_filters", "filterbank"]
-    assert list(inspect.signature(ex.main).parameters) == ["feature_set", "multiplier", "leak_variance_divisor"]
+    sig = inspect.signature(ex.main).parameters
+    assert list(sig)[:3] == ["feature_set", "multiplier", "leak_variance_divisor"]
+    # what the reference hard-codes is keyword-only here, and None means "the reference's constant"
+    assert all(p.kind is p.KEYWORD_ONLY and p.default is None for p in list(sig.values())[3:])
+    assert ex.reservoir_shape() == (1000, 400, 200) == (ex.NUM_NEURONS, ex.NUM_OUTPUT_NEURONS, ex.SMALL_WORLD_K)
     assert list(inspect.signature(ex.extract_all_features).parameters) == ["lsm", "spike_data", "feature_keys", "desc"]
     assert inspect.signature(cd.convert_spectrogram_to_spikes_hysteresis).parameters["hysteresis_gap"].default == 0.05
     np.testing.assert_array_equal(cd.create_pure_redundancy(np.eye(2, dtype=np.uint8), 2),

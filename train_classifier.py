@@ -47,9 +47,18 @@ class _TorchReadout:
         return self.model.predict(self.torch.from_numpy(np.asarray(X)).to(self.dev)).cpu().numpy()
 
 
-def train_and_evaluate_classifier(readout=None):
+READOUTS = ("sklearn", "torch-ridge", "torch-logistic")
+
+
+def train_and_evaluate_classifier(readout=None, class_names=None):
+    """The reference's function (no arguments there).  `readout`: one of READOUTS (default: LSM_READOUT, else the
+    reference's scikit-learn logistic regression); `class_names`: report names when the dataset was built with
+    another class list than the reference's 12 words (train_classifier.py:8-20 hard-codes them)."""
     from sklearn.metrics import accuracy_score, classification_report
     readout = readout or os.environ.get("LSM_READOUT", "sklearn")
+    if readout not in READOUTS:
+        raise ValueError(f"readout must be one of {READOUTS}, got {readout!r}")
+    class_names = list(CLASS_NAMES if class_names is None else class_names)
     if not Path(FEATURE_FILE).exists():
         print("Error: Dataset file not found. Please run 'extract_lsm_features.py' first.")
         return
@@ -68,7 +77,7 @@ def train_and_evaluate_classifier(readout=None):
     y_pred = clf.predict(X_test)
     accuracy = accuracy_score(y_test, y_pred)
     present = sorted(set(np.unique(y_train)) | set(np.unique(y_test)))
-    names = [CLASS_NAMES[i] if i < len(CLASS_NAMES) else f"class_{i}" for i in present]
+    names = [class_names[i] if i < len(class_names) else f"class_{i}" for i in present]
     report = classification_report(y_test, y_pred, labels=present, target_names=names, zero_division=0)
     print("\n--- Final Results ---")
     print(f"Test Accuracy: {accuracy * 100:.2f}%\n")
@@ -78,4 +87,17 @@ def train_and_evaluate_classifier(readout=None):
 
 
 if __name__ == "__main__":
-    train_and_evaluate_classifier()
+    import argparse
+    ap = argparse.ArgumentParser(description="Train and evaluate the linear readout on the LSM features.")
+    ap.add_argument("--readout", type=str, default=None, choices=READOUTS,
+                    help="default: LSM_READOUT, else scikit-learn logistic regression (the reference's readout)")
+    ap.add_argument("--commands", type=str, default=None, help="Comma-separated class names for the report.")
+    ap.add_argument("--commands-file", type=str, default=None, help="File with one class name per line.")
+    a = ap.parse_args()
+    names = None
+    if a.commands_file:
+        with open(a.commands_file) as fh:
+            names = [ln.strip() for ln in fh if ln.strip() and not ln.lstrip().startswith("#")]
+    elif a.commands:
+        names = [w.strip() for w in a.commands.split(",") if w.strip()]
+    train_and_evaluate_classifier(readout=a.readout, class_names=names)
