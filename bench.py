@@ -81,6 +81,8 @@ def parse_args(argv=None):
                          "rate; never the contract's `value`, which is quoted on HBM-resident inputs)")
     ap.add_argument("--streams", type=int, default=0,
                     help="HIP streams the steps rotate over (0 = the pipeline's default; 1 = serial)")
+    ap.add_argument("--fe-streams", type=int, default=None,
+                    help="front-end streams of their own (0 = rotation: a step keeps to one stream; default: the pipeline's)")
     ap.add_argument("--exchange", default="once", choices=["once", "per-step"],
                     help="N > 1: 'once' = every rank keeps its steps' feature rows and ONE all-gather follows the "
                          "last step, inside the timed region (what the product does: one gather per split, "
@@ -282,7 +284,7 @@ def run_rank(args):
 
     n_streams = args.streams or DEFAULT_STREAMS
     hp = HotPath(fe, net, FEATURE_SET, streams=n_streams, waves_per_clip=args.waves_per_clip,
-                 time_reservoir=True)
+                 time_reservoir=True, fe_streams=args.fe_streams)
     lay = net.layout(B, fe.n_steps, hp.waves_per_clip)
     audio_pinned = torch.from_numpy(audio_np).pin_memory() if args.from_host else None
     per_step = use_dist and args.exchange == "per-step"
@@ -404,8 +406,10 @@ def run_rank(args):
                        "waves_per_clip": lay["waves_per_clip"], "lds_bytes_per_clip": lay["lds_bytes"],
                        "inputs": "pinned host memory, copied every step" if args.from_host else "resident in HBM",
                        "host_enqueue_ms_per_step": round(host_enqueue_ms, 4),
-                       "streams": hp.n_streams, "hw_queues": hp.hw_queues,
-                       "pipeline": "pipeline.HotPath: steps rotate over the streams" if hp.n_streams > 1 else "serial",
+                       "streams": hp.n_streams, "fe_streams": hp.n_fe_streams, "hw_queues": hp.hw_queues,
+                       "pipeline": ("serial" if hp.n_streams <= 1 else
+                                    "pipeline.HotPath: steps rotate over the streams" if not hp.n_fe_streams else
+                                    "pipeline.HotPath: front ends on their own streams, reservoir launches behind events"),
                        "mean_output_spikes_per_clip": spikes_per_clip,
                        "sharding": (f"clips x{world}, one feature all-gather after the last step (as the product: one "
                                     f"gather per split)" if once else

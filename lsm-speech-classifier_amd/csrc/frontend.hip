@@ -315,6 +315,7 @@ struct FusedArgs {
     uint8_t *raster;            // (n_clips, n_filters*redundancy, time_bins*n_thr)
     int n_clips, n_samples, n_filters, nwin, hop, ncols;
     int time_bins, n_thr, redundancy, groups;
+    int skip_epilogue;          // diagnostic builds (LSM_EXPERIMENT_HOOKS) only: time the filter loop alone
     double on[MAX_THR], off[MAX_THR];
 };
 
@@ -447,6 +448,9 @@ __global__ __launch_bounds__(GT_MAX_WPB * 64) void gammatone_spikes_kernel(const
     }
 #undef LSM_RUNF
 
+#if LSM_EXPERIMENT_HOOKS
+    if (a.skip_epilogue) return;
+#endif
     // ---- the clip's max / min -----------------------------------------------------------------
     double hi = mx[0], lo = mn[0];
 #pragma unroll
@@ -908,6 +912,11 @@ LSM_API int lsm_gammatone_spikes_f64(const float *audio, int n_clips, int n_samp
     a.audio = audio; a.coefs = coefs; a.ws = static_cast<double *>(workspace); a.raster = raster;
     a.n_clips = n_clips; a.n_samples = n_samples; a.n_filters = n_filters; a.nwin = nwin; a.hop = hop;
     a.ncols = ncols; a.time_bins = time_bins; a.n_thr = n_thr; a.redundancy = redundancy; a.groups = pl.groups;
+    a.skip_epilogue = 0;
+#if LSM_EXPERIMENT_HOOKS
+    static const int skip_env = [] { const char *e = getenv("LSM_GTF_SKIP_EPILOGUE"); return e ? atoi(e) : 0; }();
+    a.skip_epilogue = skip_env;
+#endif
     // unused table entries never fire: nothing is > +inf or < -inf (the kernel compares 4 or 8 thresholds)
     for (int q = 0; q < MAX_THR; ++q) { a.on[q] = q < n_thr ? thr_on[q] : INFINITY; a.off[q] = q < n_thr ? thr_off[q] : -INFINITY; }
     const long n_waves = (long)pl.groups * n_clips;

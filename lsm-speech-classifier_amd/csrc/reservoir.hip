@@ -117,6 +117,8 @@ static int free_reservoir(lsm_reservoir *h)
     return LSM_OK;
 }
 
+static size_t ring_lds_bytes(const lsm_reservoir *h, const RingVariant &v, int T);
+
 static bool has_ring(const lsm_reservoir *h)
 {
     for (const auto &v : h->rvar)
@@ -404,11 +406,17 @@ int lsm_reservoir_create(lsm_reservoir **out, int num_neurons, int n_channels,
             }
         }
     }
-    // dense rows now, unless the table exceeds the L2 caches AND ring rows exist: auto mode then never launches
-    // the dense kernel (it falls back to the sparse one when no ring layout fits), so the 64-262 MB table and its
-    // upload would be dead weight next to the ring table
-    if (!(has_ring(h) && (size_t)N * (size_t)h->ld * 4 > RING_AUTO_MIN_DENSE_BYTES)) {
-        if ((rc = ensure_dense_rows(h))) { free_reservoir(h); return rc; }
+    // dense rows now, unless auto mode will serve this reservoir with ring rows: the table exceeds the L2 caches, ring
+    // rows exist AND one of their layouts fits a CU's LDS with room to spare (probed at 1024 time steps; the
+    // reference runs 400).  Then the 64-262 MB table and its upload would be dead weight next to the ring table
+    // (ADVICE r2); lsm_reservoir_set_kernel(2) still builds it on request.  When no ring layout fits (e.g. N = 8000
+    // with 5000 output neurons) the dense kernel is auto mode's fallback and needs its table from the start.
+    {
+        bool ring_serves = false;
+        if (has_ring(h) && (size_t)N * (size_t)h->ld * 4 > RING_AUTO_MIN_DENSE_BYTES)
+            for (const auto &v : h->rvar)
+                if (v.wpc && ring_lds_bytes(h, v, 1024) <= 160 * 1024) ring_serves = true;
+        if (!ring_serves && (rc = ensure_dense_rows(h))) { free_reservoir(h); return rc; }
     }
     *out = h;
     return LSM_OK;

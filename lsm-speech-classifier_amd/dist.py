@@ -37,8 +37,9 @@ def init(backend: str | None = None):
             torch.cuda.set_device(local_rank)
             dist.init_process_group(backend, device_id=torch.device("cuda", local_rank))
         else:
+            # a host backend does not need one GPU per rank: take this rank's GPU when the box has it, else share cuda:0
             if torch.cuda.is_available():
-                torch.cuda.set_device(local_rank)
+                torch.cuda.set_device(local_rank if local_rank < torch.cuda.device_count() else 0)
             dist.init_process_group(backend)
     return rank, local_rank, world
 
@@ -46,8 +47,11 @@ def init(backend: str | None = None):
 def local_device() -> torch.device:
     """The GPU of this rank (LOCAL_RANK; cuda:0 for a single process or under LSM_SHARE_GPU=1)."""
     _, local_rank, world = env_world()
-    if world <= 1 or os.environ.get("LSM_SHARE_GPU") == "1":
-        local_rank = 0 if world > 1 else (torch.cuda.current_device() if torch.cuda.is_available() else 0)
+    if world <= 1:
+        return torch.device("cuda", torch.cuda.current_device() if torch.cuda.is_available() else 0)
+    if os.environ.get("LSM_SHARE_GPU") == "1" or (dist.is_initialized() and dist.get_backend() != "nccl"
+                                                  and local_rank >= torch.cuda.device_count()):
+        local_rank = 0
     return torch.device("cuda", local_rank)
 
 

@@ -155,7 +155,8 @@ class SpikeFrontEnd:
         return torch.cuda.current_stream(self.device).cuda_stream
 
     def _indexed_device(self) -> torch.device:
-        return self.device
+        d = self.device                 # pinned by __init__; an instance built without it may still say "cuda"
+        return d if d.index is not None or d.type != "cuda" else torch.device("cuda", torch.cuda.current_device())
 
     def _audio(self, audio) -> torch.Tensor:
         if isinstance(audio, np.ndarray):

@@ -21,6 +21,11 @@ import numpy as np
 import torch
 
 DEFAULT_STREAMS = 6
+# front-end streams of their own (0 = rotation: every step keeps to one stream).  Measured at 128 filters / 1000
+# neurons / 256 clips (profiles/r03_stream_topology.txt): 4 + 6 streams 0.678 ms per step over 200 steps and 0.83 over
+# the driver's 20, the rotation over 6 streams 0.70 / 0.84-0.90 -- a rotation stream cannot issue its next front end
+# before its own reservoir kernel has finished, and four one-launch front ends (64 workgroups each) cover the chip.
+DEFAULT_FE_STREAMS = int(os.environ.get("LSM_FE_STREAMS", "4"))
 DEFAULT_HW_QUEUES = 12
 STAGES = ("full", "frontend", "reservoir")
 
@@ -42,7 +47,8 @@ class HotPath:
     (1 = serial: everything on the current stream)."""
 
     def __init__(self, fe, net, feature_keys=None, streams: int = DEFAULT_STREAMS,
-                 waves_per_clip: int | None = None, time_reservoir: bool = False):
+                 waves_per_clip: int | None = None, time_reservoir: bool = False,
+                 fe_streams: int | None = None):
         def norm(d):      # a tensor's device always carries its index, `torch.device("cuda")` does not
             return d if d.index is not None or d.type != "cuda" else torch.device("cuda", torch.cuda.current_device())
         if norm(fe.device) != norm(net.device):
@@ -57,9 +63,15 @@ class HotPath:
         self.waves_per_clip = (-1 if self.n_streams > 1 else 0) if waves_per_clip is None else int(waves_per_clip)
         self.time_reservoir = bool(time_reservoir)
         self.hw_queues = configure_hardware_queues()
+        # Stream topology.  fe_streams == 0 ("rotation"): step s runs front end AND reservoir on stream s % streams, so
+        # the stream cannot issue its next front end before this step's reservoir kernel has finished.
+        # fe_streams > 0 ("two stages"): the front ends go round `fe_streams` streams of their own and never wait
+        # for a reservoir kernel; step s's reservoir launch goes to reservoir stream s % streams behind an event.
+        self.n_fe_streams = (DEFAULT_FE_STREAMS if fe_streams is None else max(0, int(fe_streams))) if self.n_streams > 1 else 0
         with torch.cuda.device(self.device):
             self.streams = ([torch.cuda.Stream(device=self.device) for _ in range(self.n_streams)]
                             if self.n_streams > 1 else [None])
+            self.fe_streams = [torch.cuda.Stream(device=self.device) for _ in range(self.n_fe_streams)]
         self._step = 0
         self.reservoir_events = []          # (start, end) HIP event pairs, one per submitted step (time_reservoir)
         self._h2d = {}
@@ -105,6 +117,25 @@ class HotPath:
             with torch.cuda.device(self.device):
                 x = audio if stage == "reservoir" else self._to_device(audio, slot)
                 return self._one(x, stats_out, out, stage), cur
+        if self.n_fe_streams and stage != "reservoir":
+            # two stages: front end on its own stream, the reservoir launch behind an event on another
+            fslot = (self._step - 1) % self.n_fe_streams
+            fst = self.fe_streams[fslot]
+            with torch.cuda.device(self.device):
+                with torch.cuda.stream(fst):
+                    if after is not None:
+                        fst.wait_event(after)
+                    elif on_device:
+                        fst.wait_stream(cur)
+                    rasters = self.fe.encode(self._to_device(audio, ("fe", fslot)))
+                    if stage == "frontend":
+                        return rasters, fst
+                    done = torch.cuda.Event()
+                    done.record(fst)
+                rasters.record_stream(st)          # allocated on the front-end stream, read on the reservoir stream
+                with torch.cuda.stream(st):
+                    st.wait_event(done)
+                    return self._one(rasters, stats_out, out, "reservoir"), st
         with torch.cuda.device(self.device), torch.cuda.stream(st):
             if after is not None:
                 st.wait_event(after)
@@ -135,7 +166,7 @@ class HotPath:
         self.fork_from_current()
         events = self.reservoir_events
         self.reservoir_events = []
-        for _ in range(self.n_streams):
+        for _ in range(max(self.n_streams, self.n_fe_streams)):
             self.submit(audio, stage=stage)
         self.synchronize()
         self.reservoir_events = events
@@ -144,7 +175,7 @@ class HotPath:
         """Make every stream of the rotation wait for what the current stream has issued so far
         (inputs produced there, e.g. an upload or a reservoir build)."""
         cur = torch.cuda.current_stream(self.device)
-        for st in self.streams:
+        for st in self.streams + self.fe_streams:
             if st is not None:
                 st.wait_stream(cur)
 
@@ -152,12 +183,12 @@ class HotPath:
         """The reverse edge: the current stream waits for everything the rotation has issued (no host
         synchronisation) -- e.g. before ONE collective over the rows of many steps."""
         cur = torch.cuda.current_stream(self.device)
-        for st in self.streams:
+        for st in self.streams + self.fe_streams:
             if st is not None:
                 cur.wait_stream(st)
 
     def synchronize(self):
-        for st in self.streams:
+        for st in self.streams + self.fe_streams:
             if st is not None:
                 st.synchronize()
         torch.cuda.current_stream(self.device).synchronize()

@@ -27,12 +27,14 @@ def test_hotpath_rows_equal_the_serial_path_and_the_oracle(oracle_c):
     net = snn.SNN(None, reservoir=R.build_reservoir(p, 64))
     serial, _, _ = net.run_batch(rasters, KEYS)
     batches = [audio[lo:lo + 40] for lo in range(0, len(audio), 40)]
-    for streams in (1, 3, 6):
-        hp = pipeline.HotPath(fe, net, KEYS, streams=streams)
+    # serial, the rotation (a step keeps to one stream), and front ends on streams of their own (the default)
+    for streams, fes in ((1, None), (3, 0), (6, 0), (3, 2), (6, None)):
+        hp = pipeline.HotPath(fe, net, KEYS, streams=streams, fe_streams=fes)
         assert hp.waves_per_clip == (-1 if streams > 1 else 0)
+        assert hp.n_fe_streams == (0 if streams == 1 else pipeline.DEFAULT_FE_STREAMS if fes is None else fes)
         for src in (batches, [torch.from_numpy(b).cuda() for b in batches]):       # host and device inputs
             got = hp.run(src)
-            assert torch.equal(got, serial), streams
+            assert torch.equal(got, serial), (streams, fes)
     # the layout the library picks inside a pipeline: fewer, fatter waves than for a lone launch of 256 clips
     assert net.layout(256, 400, -1)["waves_per_clip"] == 4 and net.layout(256, 400, 0)["waves_per_clip"] == 8
     ref = oracle_c.lif_run_batch(net.reservoir, rasters[:4].cpu().numpy(), KEYS, n_threads=4)

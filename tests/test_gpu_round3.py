@@ -107,8 +107,8 @@ def test_hotpath_stage_hook_ordering_and_out_rows(torch_cuda, oracle_c):
     net = snn.SNN(None, reservoir=R.build_reservoir(p, 64))
     want, _, _ = net.run_batch(rasters, KEYS)
     dev_audio = torch.from_numpy(audio).cuda()
-    for streams in (1, 4):
-        hp = pipeline.HotPath(fe, net, KEYS, streams=streams)
+    for streams, fes in ((1, None), (4, 0), (4, 3)):
+        hp = pipeline.HotPath(fe, net, KEYS, streams=streams, fe_streams=fes)
         assert hp.hw_queues == 12
         # the public stage hook goes through the same rotation and launches as a full step
         r, st = hp.submit(dev_audio, stage="frontend")
@@ -138,6 +138,6 @@ def test_hotpath_stage_hook_ordering_and_out_rows(torch_cuda, oracle_c):
             ev.record()
             f, st = hp.submit(late, after=ev if use_event else None)
             st.synchronize()
-            assert torch.equal(f, want), (streams, use_event)
+            assert torch.equal(f, want), (streams, fes, use_event)
     ref = oracle_c.lif_run_batch(net.reservoir, rasters[:3].cpu().numpy(), KEYS, n_threads=3)
     np.testing.assert_array_equal(want[:3].cpu().numpy(), ref)
