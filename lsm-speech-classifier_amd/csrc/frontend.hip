@@ -316,6 +316,7 @@ struct FusedArgs {
     int n_clips, n_samples, n_filters, nwin, hop, ncols;
     int time_bins, n_thr, redundancy, groups;
     int skip_epilogue;          // diagnostic builds (LSM_EXPERIMENT_HOOKS) only: time the filter loop alone
+    int prio;                   // wave priority of the filter loop (s_setprio 0..3)
     double on[MAX_THR], off[MAX_THR];
 };
 
@@ -414,6 +415,13 @@ __global__ __launch_bounds__(GT_MAX_WPB * 64) void gammatone_spikes_kernel(const
 
     // scratch of this wave: column c, chain q at wsw[(c * NG + q) * 64]
     double *wsw = a.ws + ((size_t)b * ncols * NG + (size_t)g * NCH) * 64 + lane;
+    // The filter loop is the throughput-critical stream of the pipeline: a wave alone on its SIMD issues a float64
+    // operation every 5.0 cycles, which leaves the reservoir waves sharing the SIMD one issue slot in five -- about
+    // what they need.  At the default priority the reservoir kernel's raised-priority phases (lif_dense.h) take
+    // slots from it instead.
+    if (a.prio == 1) __builtin_amdgcn_s_setprio(1);
+    else if (a.prio == 2) __builtin_amdgcn_s_setprio(2);
+    else if (a.prio == 3) __builtin_amdgcn_s_setprio(3);
     if (valid) {
         const int pos = nwin - (NW - 1) * hop;
         const int n_end = (ncols - 1) * hop + nwin;
@@ -448,6 +456,7 @@ __global__ __launch_bounds__(GT_MAX_WPB * 64) void gammatone_spikes_kernel(const
     }
 #undef LSM_RUNF
 
+    __builtin_amdgcn_s_setprio(0);
 #if LSM_EXPERIMENT_HOOKS
     if (a.skip_epilogue) return;
 #endif
@@ -851,6 +860,8 @@ LSM_API int lsm_gammatone_spec_f64(const float *audio, int n_clips, int n_sample
     return LSM_OK;
 }
 
+constexpr int GTF_DEFAULT_PRIO = 0;
+
 // Layout of the fused launch for `n_filters`: chains per lane, waves per clip, waves per workgroup.
 struct FusedPlan { int nch, groups, wpb; };
 static bool fused_plan(int n_filters, FusedPlan *p)
@@ -913,7 +924,10 @@ LSM_API int lsm_gammatone_spikes_f64(const float *audio, int n_clips, int n_samp
     a.n_clips = n_clips; a.n_samples = n_samples; a.n_filters = n_filters; a.nwin = nwin; a.hop = hop;
     a.ncols = ncols; a.time_bins = time_bins; a.n_thr = n_thr; a.redundancy = redundancy; a.groups = pl.groups;
     a.skip_epilogue = 0;
+    a.prio = GTF_DEFAULT_PRIO;
 #if LSM_EXPERIMENT_HOOKS
+    static const int prio_env = [] { const char *e = getenv("LSM_GTF_PRIO"); return e ? atoi(e) : -1; }();
+    if (prio_env >= 0 && prio_env <= 3) a.prio = prio_env;
     static const int skip_env = [] { const char *e = getenv("LSM_GTF_SKIP_EPILOGUE"); return e ? atoi(e) : 0; }();
     a.skip_epilogue = skip_env;
 #endif

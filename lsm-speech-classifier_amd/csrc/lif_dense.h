@@ -335,7 +335,7 @@ __global__ __launch_bounds__(WPC * 64) void lif_dense_kernel(const DenseArgs a)
         if (!drove) input_drive(t);
         if (!INMASK) wave_lds_fence();
 
-#ifndef LSM_LIF_NO_PRIO
+#if !defined(LSM_LIF_NO_PRIO) && !defined(LSM_LIF_PRIO_WHOLE)   // (PRIO_WHOLE: diagnostic build, raised for the whole step)
         __builtin_amdgcn_s_setprio(0);
 #endif
         // ---- neuron update ----

@@ -22,10 +22,12 @@ import torch
 
 DEFAULT_STREAMS = 6
 # front-end streams of their own (0 = rotation: every step keeps to one stream).  Measured at 128 filters / 1000
-# neurons / 256 clips (profiles/r03_stream_topology.txt): 4 + 6 streams 0.678 ms per step over 200 steps and 0.83 over
-# the driver's 20, the rotation over 6 streams 0.70 / 0.84-0.90 -- a rotation stream cannot issue its next front end
-# before its own reservoir kernel has finished, and four one-launch front ends (64 workgroups each) cover the chip.
-DEFAULT_FE_STREAMS = int(os.environ.get("LSM_FE_STREAMS", "4"))
+# neurons / 256 clips (profiles/r03_stream_topology.txt, r03_priorities_and_stream_counts.txt): 5 + 6 streams 0.65 ms
+# per step over 200 steps and 0.80-0.81 over the driver's 20, 4 + 6 streams 0.66 / 0.82-0.83, the rotation over 6
+# streams 0.70 / 0.86-0.90 on the same box -- a rotation stream cannot issue its next front end before its own
+# reservoir kernel has finished; four one-launch front ends (64 workgroups each, one per CU) cover the chip and the
+# fifth is already queued when the first CUs come free.  5 + 6 + the default stream = the 12 hardware queues.
+DEFAULT_FE_STREAMS = int(os.environ.get("LSM_FE_STREAMS", "5"))
 DEFAULT_HW_QUEUES = 12
 STAGES = ("full", "frontend", "reservoir")
 

@@ -51,7 +51,7 @@ def test_bench_line_names_the_committed_traffic_file_at_the_headline_shape():
     assert r["traffic"] > 0 and "profiles/lif_traffic.json[cfg2_B256_dense]" in r["traffic_source"]
     assert "not measured in this run" in r["traffic_source"]
     assert 0 < r["memory_side_frac"] < 1 and r["memory_side_gbs_lone_launch"] > 0
-    assert d["config"]["hw_queues"] == 12 and d["config"]["streams"] == 6 and d["config"]["fe_streams"] == 4
+    assert d["config"]["hw_queues"] == 12 and d["config"]["streams"] == 6 and d["config"]["fe_streams"] == 5
 
 
 def test_bench_stages_and_serial_mode():

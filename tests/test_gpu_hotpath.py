@@ -64,16 +64,21 @@ def test_in_memory_route_writes_the_same_file_2(tmp_path, monkeypatch):
         assert str(d["feature_set"]) == "original"
 
 
-def test_bench_spawns_two_ranks_on_a_shared_gpu():
+@pytest.mark.parametrize("exchange", ["once", "per-step"])
+def test_bench_spawns_two_ranks_on_a_shared_gpu(exchange):
+    """`bench.py --gpus 2` starts its own ranks; both exchange modes: ONE all-gather of every step's rows after the
+    last step (the default: what the product does per split) and an all-gather behind every step."""
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
     env.update(LSM_BENCH_SHARE_GPU="1", LSM_BENCH_BACKEND="gloo")
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "2",
-                        "--batch", "64", "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=600)
+                        "--batch", "64", "--no-cpu-baseline", "--exchange", exchange], env=env, capture_output=True,
+                       text=True, timeout=600)
     assert p.returncode == 0, p.stderr[-3000:]
     lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["config"]["clips_per_gpu"] == 64 and "all-gather" in d["config"]["sharding"]
+    assert ("after the last step" in d["config"]["sharding"]) == (exchange == "once")
     assert abs(d["value"] - 2 * 64 / (d["ms_per_step"] * 1e-3)) / d["value"] < 1e-3
 
 
