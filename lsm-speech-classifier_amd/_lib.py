@@ -21,7 +21,7 @@ _SIGS = {
                                        c_void, c_void, c_int, c_void]),
     "lsm_gammatone_spikes_workspace": (C.c_long, [c_int, c_int, c_int]),
     "lsm_gammatone_spikes_f64": (c_int, [c_void, c_int, c_int, c_void, c_int, c_int, c_int, c_int, c_int,
-                                         c_void, c_void, c_int, c_int, c_void, c_void, C.c_long, c_int, c_void]),
+                                         c_void, c_void, c_int, c_int, c_void, c_void, C.c_long, c_int, c_int, c_void]),
     "lsm_spec_to_spikes_f64": (c_int, [c_void, c_int, c_int, c_int, c_int, c_int, c_void, c_void,
                                        c_int, c_int, c_void, c_void, c_void]),
     "lsm_spec_to_spikes_f32": (c_int, [c_void, c_int, c_int, c_int, c_int, c_int, c_void, c_void,

@@ -294,15 +294,15 @@ __global__ __launch_bounds__(WPC * 64) void lif_ring_kernel(const RingArgs a)
                 const int base = (g0 + QL - 1 < q0) ? g0 - q0 + NQ : g0 - q0;
                 p_soff = (uint32_t)((base * 256 - lead) * 4);           // negative: wraps to > any num_records
             }
-            const uint64_t baddr = band_base + (uint64_t)(uint32_t)jl * a.pitch;
-            const uint32_t p_blo = (uint32_t)baddr, p_bhi = (uint32_t)(baddr >> 32);
+            // Three packed words per row instead of seven values: the 64-bit addresses are formed per row by the
+            // SCALAR unit (the kernel is bound by vector-instruction issue at N = 4000; v_readlane is a vector
+            // instruction, s_mul/s_add are not): A = row | bytes/16 << 16, B = offset word, C = list start | count << 24.
             // (lanes past the chunk's end look at row 0: a valid address, and `live` voids their rows below --
             //  no branch around these loads)
             const uint32_t r0 = a.rem_ptr[jl * WPC + w];
             const uint32_t r1 = a.rem_ptr[jl * WPC + w + 1];
-            const uint64_t raddr = rem_base + (uint64_t)r0 * 8u;
-            const uint32_t p_rlo = (uint32_t)raddr, p_rhi = (uint32_t)(raddr >> 32);
-            const uint32_t p_rnrec = (r1 - r0) * 8u;
+            const uint32_t p_a = (uint32_t)jl | ((p_nrec >> 4) << 16);
+            const uint32_t p_c = r0 | ((r1 - r0) << 24);                // host: fewer than 2^24 list entries per layout
             const int n = (int)min(64u, total - l0);
             ring_f4 wv[P][WL];
             ring_u2 re[P];
@@ -317,12 +317,12 @@ __global__ __launch_bounds__(WPC * 64) void lif_ring_kernel(const RingArgs a)
     {                                                                                           \
         const int mm = (m) & 63;                                                                \
         const uint32_t live = (uint32_t) - (int)((m) < n);                                      \
-        const uint32_t blo = __builtin_amdgcn_readlane(p_blo, mm);                              \
-        const uint32_t bhi = __builtin_amdgcn_readlane(p_bhi, mm);                              \
-        const uint32_t nrec = __builtin_amdgcn_readlane(p_nrec, mm) & live;                     \
+        const uint32_t ra = __builtin_amdgcn_readlane(p_a, mm);                                 \
         const uint32_t soff = __builtin_amdgcn_readlane(p_soff, mm);                            \
+        const uint32_t nrec = ((ra >> 16) << 4) & live;                                         \
+        const uint64_t baddr = band_base + (uint64_t)((ra & 0xFFFFu) * a.pitch);                \
         const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc(                    \
-            reinterpret_cast<void *>(((uint64_t)bhi << 32) | blo), 0, (int)nrec, RSRC_FLAGS);   \
+            reinterpret_cast<void *>(baddr), 0, (int)nrec, RSRC_FLAGS);                         \
         qh[p] = soff & 15u;                                                                     \
         _Pragma("unroll") for (int q = 0; q < WL; ++q) {                                        \
             /* the whole byte offset goes through the VGPR (opaque scalar: nothing is folded into the    */ \
@@ -343,11 +343,11 @@ __global__ __launch_bounds__(WPC * 64) void lif_ring_kernel(const RingArgs a)
     {                                                                                           \
         const int mm = (m) & 63;                                                                \
         const uint32_t live = (uint32_t) - (int)((m) < n);                                      \
-        const uint32_t rlo = __builtin_amdgcn_readlane(p_rlo, mm);                              \
-        const uint32_t rhi = __builtin_amdgcn_readlane(p_rhi, mm);                              \
-        const uint32_t rnrec = __builtin_amdgcn_readlane(p_rnrec, mm) & live;                   \
+        const uint32_t rc = __builtin_amdgcn_readlane(p_c, mm);                                 \
+        const uint32_t rnrec = ((rc >> 24) << 3) & live;                                        \
+        const uint64_t raddr = rem_base + (uint64_t)((rc & 0xFFFFFFu) << 3);                    \
         const __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc(                    \
-            reinterpret_cast<void *>(((uint64_t)rhi << 32) | rlo), 0, (int)rnrec, RSRC_FLAGS);  \
+            reinterpret_cast<void *>(raddr), 0, (int)rnrec, RSRC_FLAGS);                        \
         if (LSM_RING_ABLATE & 8) re[p] = (ring_u2){0u, 0u};                                     \
         else re[p] = __builtin_amdgcn_raw_buffer_load_b64(rr, (int)lane8, 0, 0);                \
         __builtin_amdgcn_sched_barrier(0);                                                      \

@@ -368,6 +368,7 @@ int lsm_reservoir_create(lsm_reservoir **out, int num_neurons, int n_channels,
                                 emax = std::max(emax, (int)++rptr[(size_t)j * wpc + wave_of(csc_post[e]) + 1]);
                     if (emax > 64) continue;                             // one lane per list entry
                     for (size_t q = 1; q < rptr.size(); ++q) rptr[q] += rptr[q - 1];
+                    if (rptr.back() >= (1u << 24)) continue;             // the kernel packs a list's start into 24 bits
                     std::vector<uint2> rem(std::max<size_t>(1, rptr.back()));
                     std::vector<uint32_t> fill(rptr.begin(), rptr.end() - 1);
                     for (int j = 0; j < N; ++j)

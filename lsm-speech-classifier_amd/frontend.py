@@ -206,10 +206,12 @@ class SpikeFrontEnd:
                           _dev(norm) if want_norm else None, self._stream()), "lsm_spec_to_spikes")
         return raster, norm
 
-    def encode(self, audio, fused: bool | None = None) -> torch.Tensor:
+    def encode(self, audio, fused: bool | None = None, low_latency: bool = False) -> torch.Tensor:
         """audio (B, n_samples) -> uint8 spike raster (B, C, n_steps) on the device.  The gammatone branch
         is one launch (`lsm_gammatone_spikes_f64`); `fused=False` takes the two split entry points
-        (identical rasters), which is also what the mel branch and > 1024 filters use."""
+        (identical rasters), which is also what the mel branch and > 1024 filters use.  `low_latency`: the
+        fused launch in its one-chain layout (twice the waves, each half as long) -- for a batch that meets an idle
+        GPU; `pipeline.HotPath` asks for it when none of its front ends is in flight."""
         if fused is None:
             # LSM_FRONTEND_SPLIT=1: diagnostic switch for same-box A/B runs of the two routes (exp/r03_fused_sweep.sh)
             fused = (self.filterbank == "gammatone" and self.n_filters <= 1024
@@ -230,7 +232,8 @@ class SpikeFrontEnd:
             _lib.check(self.lib.lsm_gammatone_spikes_f64(
                 _dev(audio), B, self.n_samples, _dev(self.coefs), self.n_filters, self.nwin, self.hop,
                 self.ncols, self.time_bins, _host(on), _host(off), len(on), self.redundancy, _dev(raster),
-                _dev(ws), ws_bytes, self.coef_flags, self._stream()), "lsm_gammatone_spikes_f64")
+                _dev(ws), ws_bytes, self.coef_flags, 1 if low_latency else 0, self._stream()),
+                "lsm_gammatone_spikes_f64")
         return raster
 
 

@@ -43,6 +43,7 @@ def test_fused_front_end_matches_oracle_and_split_path(torch_cuda, oracle_c, n_f
     split = fe.encode(audio, fused=False)
     assert fused.shape == (len(audio), n_filters, 400) and fused.dtype == torch_cuda.uint8
     assert torch_cuda.equal(fused, split)
+    assert torch_cuda.equal(fused, fe.encode(audio, fused=True, low_latency=True))   # one chain per lane
     got = fused.cpu().numpy()
     assert not got[2].any()
     np.testing.assert_array_equal(got, _oracle_raster(oracle_c, audio, n_filters))
@@ -106,8 +107,12 @@ def test_fused_argument_errors(torch_cuda):
     h = lambda a: C.c_void_p(a.ctypes.data)
     call = lambda **kw: lib.lsm_gammatone_spikes_f64(
         p(audio), kw.get("B", 4), 16000, p(fe.coefs), 128, 400, 160, 98, 100, h(on), h(off), kw.get("n_thr", 4),
-        kw.get("red", 1), kw.get("raster", p(raster)), p(ws), kw.get("ws_bytes", need), fe.coef_flags, None)
+        kw.get("red", 1), kw.get("raster", p(raster)), p(ws), kw.get("ws_bytes", need), fe.coef_flags,
+        kw.get("flags", 0), None)
     assert call() == 0
+    want = raster.clone()
+    assert call(flags=1) == 0 and torch_cuda.equal(raster, want)      # the low-latency layout: same raster
+    assert call(flags=2) == -1
     assert call(B=0) == 0
     assert call(ws_bytes=need - 8) == -1 and b"workspace" in lib.lsm_last_error()
     assert call(n_thr=9) == -1
