@@ -288,6 +288,14 @@ def run_rank(args):
     lay = net.layout(B, fe.n_steps, hp.waves_per_clip)
     audio_pinned = torch.from_numpy(audio_np).pin_memory() if args.from_host else None
     per_step = use_dist and args.exchange == "per-step"
+    # one exchange keeps every step's rows of every rank in one block: fall back to the per-step gather when that block
+    # would not be small next to the HBM (cfg5 over hundreds of steps), and say so in config.sharding
+    gather_block_bytes = world * max(args.steps, 1) * B * n_feat * 4
+    if use_dist and not per_step and gather_block_bytes > (16 << 30):
+        per_step = True
+        if rank == 0:
+            print(f"bench.py: one exchange would need a {gather_block_bytes / 2**30:.1f} GiB gather block; "
+                  f"gathering behind every step instead", file=sys.stderr)
     once = use_dist and not per_step
     stage_in = rasters0 if args.stage == "reservoir" else (audio_pinned if args.from_host else audio)
     # per-step exchange: one gather buffer per stream of the rotation (overlapping steps never share an output);
@@ -471,20 +479,26 @@ def run_rank(args):
                 round(traffic / (lone_ms * 1e-3) / 1e9 / ceiling, 4),
             }
             if gt_ms is not None:
-                # the kernel that takes most of the GPU time is the float64 filterbank, bound by vector-ALU issue:
-                # 36 instructions per sample and channel, none fusable into FMAs without changing the rounding
-                ops = 36.0 * ((fe.ncols - 1) * fe.hop + fe.nwin) * cfg["n_filters"] * B
+                # the kernel that takes most of the GPU time is the float64 filterbank, bound by vector-ALU issue: 36
+                # instructions per sample and channel (35.5 in the one-launch front end above 64 filters: two channels
+                # per lane share the sample's conversion), none fusable into FMAs without changing the rounding
+                fused = os.environ.get("LSM_FRONTEND_SPLIT") != "1" and cfg["n_filters"] <= 1024
+                two_chains = fused and cfg["n_filters"] > 64
+                ops = (35.5 if two_chains else 36.0) * ((fe.ncols - 1) * fe.hop + fe.nwin) * cfg["n_filters"] * B
+                k_ms = fe_ms if fused else gt_ms        # the launch the pipeline runs: whole fused front end, or filterbank
                 line["roofline"]["dominant_kernel_by_time"] = {
-                    "kernel": "gammatone_kernel", "bound": "valu_f64",
-                    "idle_gpu_ms": round(gt_ms, 4), "frontend_idle_gpu_ms": round(fe_ms, 4),
-                    "achieved": round(ops / (gt_ms * 1e-3) / 1e12, 2), "peak": F64_UNFUSED_PEAK_TOPS,
-                    "unit": "T f64 instr-lanes/s", "frac": round(ops / (gt_ms * 1e-3) / 1e12 / F64_UNFUSED_PEAK_TOPS, 4),
+                    "kernel": "gammatone_spikes_kernel" if fused else "gammatone_kernel", "bound": "valu_f64",
+                    "idle_gpu_ms": round(k_ms, 4), "frontend_idle_gpu_ms": round(fe_ms, 4),
+                    "split_filterbank_idle_gpu_ms": round(gt_ms, 4),
+                    "achieved": round(ops / (k_ms * 1e-3) / 1e12, 2), "peak": F64_UNFUSED_PEAK_TOPS,
+                    "unit": "T f64 instr-lanes/s", "frac": round(ops / (k_ms * 1e-3) / 1e12 / F64_UNFUSED_PEAK_TOPS, 4),
                     "pipeline_achieved": round(ops / (ms_step * 1e-3) / 1e12, 2),
                     "pipeline_frac": round(ops / (ms_step * 1e-3) / 1e12 / F64_UNFUSED_PEAK_TOPS, 4),
-                    "waves": -(-cfg["n_filters"] // 64) * B,
+                    "waves": -(-cfg["n_filters"] // (128 if two_chains else 64)) * B,
                     "note": "peak = one float64 operation per lane and instruction on all 1024 SIMDs with >= 4 waves "
-                            "each (78.6 TFLOPS counts an FMA as two); idle_gpu = the kernel alone, pipeline = the same "
-                            "instruction count over the measured step time of the whole overlapped path",
+                            "each (78.6 TFLOPS counts an FMA as two); idle_gpu = ONE launch alone (the one-launch front end "
+                            "occupies a quarter of the chip at 128 filters / 256 clips: four in flight cover it), pipeline = "
+                            "the same instruction count over the measured step time of the whole overlapped path",
                 }
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(cfg, audio_np, res)

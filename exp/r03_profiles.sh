@@ -12,7 +12,7 @@ $B > $OUT/bench_default.json 2> $OUT/bench_default.err && echo "bench default (2
 $B --no-cpu-baseline --streams 1 > $OUT/bench_serial.json 2> $OUT/bench_serial.err && echo "bench serial done"
 # same-box A/B: the two split launches of round 2 against the one-launch front end, rotation against two stages
 for rep in 1 2; do
-  for V in "split_rotation LSM_FRONTEND_SPLIT=1 --fe-streams 0" "fused_rotation LSM_X=0 --fe-streams 0" "fused_two_stages LSM_X=0 --fe-streams 4"; do
+  for V in "split_rotation LSM_FRONTEND_SPLIT=1 --fe-streams 0" "fused_rotation LSM_X=0 --fe-streams 0" "fused_two_stages LSM_X=0 --fe-streams 5"; do
     set -- $V
     for A in "--steps 20 --warmup 5" "--steps 200 --warmup 12"; do
       env $2 $B $A $3 $4 --no-cpu-baseline 2>/dev/null | python3 -c "
