@@ -81,6 +81,13 @@ class HotPath:
         self.wide_when_idle = os.environ.get("LSM_FE_WIDE_WHEN_IDLE", "1") != "0"
         self._wide_below = int(os.environ.get("LSM_FE_WIDE_BELOW", "1"))     # diagnostic: front ends in flight below which the wide layout goes out
         self._fe_done = []                  # events of the front ends issued, newest last (two-stage topology)
+        # Back-pressure: the host enqueues a step in ~60 us, the GPU runs it in ~640: without a bound a long run is
+        # enqueued thousands of steps ahead, and every step's raster (handed from its front-end stream to its reservoir
+        # stream, so the allocator may only reuse it once the reservoir launch has FINISHED) stays reserved until then:
+        # 13 MB x steps in flight (measured: 12 GB after 3000 steps).  submit() therefore waits for step s - max_ahead
+        # before it issues step s; the GPU keeps max_ahead steps queued, which is far more than it overlaps.
+        self.max_ahead = max(16, 4 * (self.n_streams + self.n_fe_streams))
+        self._in_flight = []                # one event per submitted step, on the stream its last launch went to
         self._step = 0
         self.reservoir_events = []          # (start, end) HIP event pairs, one per submitted step (time_reservoir)
         self._h2d = {}
@@ -112,12 +119,24 @@ class HotPath:
         `out`: write the rows into this (B, n_feat) float32 tensor (a slice of a gather buffer) instead of a new one.
         `stage`: "full"; "frontend" (returns the uint8 rasters; `out`/`stats_out` unused); "reservoir" (`audio` IS a
         uint8 raster batch (B, C, T) on the device) -- the same rotation, launches and layout hint as a full step,
-        so that per-stage timings go through the code the headline goes through."""
+        so that per-stage timings go through the code the headline goes through.
+        Back-pressure: when `max_ahead` earlier steps have not finished, submit() first waits for the oldest."""
+        res, st = self._submit(audio, stats_out, after, out, stage)
+        if st is not None and self.n_streams > 1:
+            ev = torch.cuda.Event()
+            ev.record(st)
+            self._in_flight.append(ev)
+        return res, st
+
+    def _submit(self, audio, stats_out=None, after=None, out=None, stage: str = "full"):
+        """submit() without the in-flight bookkeeping."""
         if stage not in STAGES:
             raise ValueError(f"stage must be one of {STAGES}, got {stage!r}")
         slot = self._step % self.n_streams
         st = self.streams[slot]
         self._step += 1
+        while len(self._in_flight) >= self.max_ahead:
+            self._in_flight.pop(0).synchronize()
         cur = torch.cuda.current_stream(self.device)
         on_device = torch.is_tensor(audio) and audio.device == self.device
         if st is None:
@@ -202,6 +221,7 @@ class HotPath:
                 cur.wait_stream(st)
 
     def synchronize(self):
+        self._in_flight.clear()
         for st in self.streams + self.fe_streams:
             if st is not None:
                 st.synchronize()
