@@ -158,6 +158,12 @@ class SpikeFrontEnd:
         d = self.device                 # pinned by __init__; an instance built without it may still say "cuda"
         return d if d.index is not None or d.type != "cuda" else torch.device("cuda", torch.cuda.current_device())
 
+    def workspace_elems(self, n_clips: int) -> int:
+        """float64 elements of the fused launch's scratch for a batch of `n_clips` (0 for the mel branch)."""
+        if self.filterbank != "gammatone":
+            return 0
+        return max(int(self.lib.lsm_gammatone_spikes_workspace(int(n_clips), self.n_filters, self.ncols)), 8) // 8
+
     def _audio(self, audio) -> torch.Tensor:
         if isinstance(audio, np.ndarray):
             audio = torch.from_numpy(np.ascontiguousarray(audio, dtype=np.float32))
@@ -206,12 +212,15 @@ class SpikeFrontEnd:
                           _dev(norm) if want_norm else None, self._stream()), "lsm_spec_to_spikes")
         return raster, norm
 
-    def encode(self, audio, fused: bool | None = None, low_latency: bool = False) -> torch.Tensor:
+    def encode(self, audio, fused: bool | None = None, low_latency: bool = False,
+               raster_out: torch.Tensor | None = None, workspace: torch.Tensor | None = None) -> torch.Tensor:
         """audio (B, n_samples) -> uint8 spike raster (B, C, n_steps) on the device.  The gammatone branch
         is one launch (`lsm_gammatone_spikes_f64`); `fused=False` takes the two split entry points
         (identical rasters), which is also what the mel branch and > 1024 filters use.  `low_latency`: the
         fused launch in its one-chain layout (twice the waves, each half as long) -- for a batch that meets an idle
-        GPU; `pipeline.HotPath` asks for it when none of its front ends is in flight."""
+        GPU; `pipeline.HotPath` asks for it when none of its front ends is in flight.  `raster_out` / `workspace`
+        (fused launch only): caller-owned uint8 (B, C, n_steps) output and float64 scratch of at least
+        `workspace_elems(B)` elements, so that a steady stream of batches makes no allocator call at all."""
         if fused is None:
             # LSM_FRONTEND_SPLIT=1: diagnostic switch for same-box A/B runs of the two routes (exp/r03_fused_sweep.sh)
             fused = (self.filterbank == "gammatone" and self.n_filters <= 1024
@@ -226,9 +235,22 @@ class SpikeFrontEnd:
         B = audio.shape[0]
         on, off = threshold_tables(self.thresholds, self.gap, np.float64)
         with torch.cuda.device(self.device):
-            raster = torch.empty((B, self.n_channels, self.n_steps), dtype=torch.uint8, device=self.device)
+            shape = (B, self.n_channels, self.n_steps)
+            if raster_out is not None:
+                if (raster_out.dtype != torch.uint8 or tuple(raster_out.shape) != shape or not raster_out.is_contiguous()
+                        or raster_out.device != self.device):
+                    raise ValueError(f"raster_out must be a contiguous uint8 {shape} tensor on {self.device}")
+                raster = raster_out
+            else:
+                raster = torch.empty(shape, dtype=torch.uint8, device=self.device)
             ws_bytes = int(self.lib.lsm_gammatone_spikes_workspace(B, self.n_filters, self.ncols))
-            ws = torch.empty((max(ws_bytes, 8) // 8,), dtype=torch.float64, device=self.device)
+            if workspace is not None:
+                if (workspace.dtype != torch.float64 or workspace.numel() * 8 < ws_bytes or not workspace.is_contiguous()
+                        or workspace.device != self.device):
+                    raise ValueError(f"workspace must be a contiguous float64 tensor of >= {ws_bytes // 8} elements on {self.device}")
+                ws = workspace
+            else:
+                ws = torch.empty((max(ws_bytes, 8) // 8,), dtype=torch.float64, device=self.device)
             _lib.check(self.lib.lsm_gammatone_spikes_f64(
                 _dev(audio), B, self.n_samples, _dev(self.coefs), self.n_filters, self.nwin, self.hop,
                 self.ncols, self.time_bins, _host(on), _host(off), len(on), self.redundancy, _dev(raster),

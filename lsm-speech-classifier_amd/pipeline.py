@@ -29,6 +29,7 @@ DEFAULT_STREAMS = 6
 # fifth is already queued when the first CUs come free.  5 + 6 + the default stream = the 12 hardware queues.
 DEFAULT_FE_STREAMS = int(os.environ.get("LSM_FE_STREAMS", "5"))
 DEFAULT_HW_QUEUES = 12
+RASTER_DEPTH = 4                     # raster buffers per front-end stream (two-stage topology)
 STAGES = ("full", "frontend", "reservoir")
 
 
@@ -87,6 +88,15 @@ class HotPath:
         # 13 MB x steps in flight (measured: 12 GB after 3000 steps).  submit() therefore waits for step s - max_ahead
         # before it issues step s; the GPU keeps max_ahead steps queued, which is far more than it overlaps.
         self.max_ahead = max(16, 4 * (self.n_streams + self.n_fe_streams))
+        # Two-stage topology: the rasters and the front end's scratch live in buffers the pipeline owns, RASTER_DEPTH
+        # rasters and one scratch per front-end stream, handed round behind events -- a raster buffer is written again
+        # only after the reservoir launch that read it has finished (a GPU-side wait of the front-end stream, never
+        # a host wait).  Allocating them per step from torch's allocator would need the block of step s to stay
+        # reserved until its reservoir launch has finished on ANOTHER stream (`record_stream`), so a burst of steps
+        # enqueued ahead of the GPU calls hipMalloc inside the burst -- and hipMalloc stalls every queue.
+        self.pool = os.environ.get("LSM_HOTPATH_POOL", "1") != "0"
+        self._rasters = {}                  # (front-end slot, batch size) -> [buffers], [events "free again"], next index
+        self._ws = {}                       # (front-end slot, batch size) -> scratch
         self._in_flight = []                # one event per submitted step, on the stream its last launch went to
         self._step = 0
         self.reservoir_events = []          # (start, end) HIP event pairs, one per submitted step (time_reservoir)
@@ -159,16 +169,39 @@ class HotPath:
                     idle = (self.wide_when_idle and len(self._fe_done) < self._wide_below
                             and getattr(self.fe, "filterbank", "") == "gammatone")
                     x = self._to_device(audio, ("fe", fslot))
-                    rasters = self.fe.encode(x, low_latency=True) if idle else self.fe.encode(x)
+                    pooled = self.pool and stage == "full" and getattr(self.fe, "filterbank", "") == "gammatone"
+                    if pooled:
+                        key = (fslot, int(x.shape[0]))
+                        ring = self._rasters.get(key)
+                        if ring is None:
+                            ring = self._rasters[key] = [
+                                [torch.empty((x.shape[0], self.fe.n_channels, self.fe.n_steps), dtype=torch.uint8,
+                                             device=self.device) for _ in range(RASTER_DEPTH)],
+                                [None] * RASTER_DEPTH, 0]
+                            self._ws[key] = torch.empty((self.fe.workspace_elems(x.shape[0]),), dtype=torch.float64,
+                                                        device=self.device)
+                        bi = ring[2]
+                        ring[2] = (bi + 1) % RASTER_DEPTH
+                        if ring[1][bi] is not None:
+                            fst.wait_event(ring[1][bi])          # its last reader (a reservoir launch) has finished
+                        rasters = self.fe.encode(x, low_latency=idle, raster_out=ring[0][bi], workspace=self._ws[key])
+                    else:
+                        rasters = self.fe.encode(x, low_latency=True) if idle else self.fe.encode(x)
                     done = torch.cuda.Event()
                     done.record(fst)
                     self._fe_done.append(done)
                     if stage == "frontend":
                         return rasters, fst
-                rasters.record_stream(st)          # allocated on the front-end stream, read on the reservoir stream
+                if not pooled:
+                    rasters.record_stream(st)      # allocated on the front-end stream, read on the reservoir stream
                 with torch.cuda.stream(st):
                     st.wait_event(done)
-                    return self._one(rasters, stats_out, out, "reservoir"), st
+                    feats = self._one(rasters, stats_out, out, "reservoir")
+                    if pooled:
+                        free = torch.cuda.Event()
+                        free.record(st)
+                        ring[1][bi] = free
+                    return feats, st
         with torch.cuda.device(self.device), torch.cuda.stream(st):
             if after is not None:
                 st.wait_event(after)
