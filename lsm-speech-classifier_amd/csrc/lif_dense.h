@@ -67,8 +67,19 @@ struct DenseArgs {
 //      popcount(mask & row) against the step's wave-uniform input bit row: no atomics, no count array,
 //      and nothing to wait for between the recurrent rows and the update
 // (Ring-like reservoirs whose dense table no longer fits the caches run on lif_ring.h instead: window + list rows.)
+// LSM_DENSE_MAX_VGPR: register cap of the kernel (0 = the compiler's choice).  Inside the pipeline a reservoir wave
+// shares its SIMD with a front-end wave of 160-168 registers: at <= 112 registers THREE reservoir workgroups fit beside
+// it (168 + 3 x 112 <= 512), at the compiler's 113 (allocated in steps of 8: 120) only two.
+#ifndef LSM_DENSE_MAX_VGPR
+#define LSM_DENSE_MAX_VGPR 0
+#endif
+#if LSM_DENSE_MAX_VGPR
+#define LSM_DENSE_VGPR_ATTR __attribute__((amdgpu_waves_per_eu(512 / LSM_DENSE_MAX_VGPR)))
+#else
+#define LSM_DENSE_VGPR_ATTR
+#endif
 template <int SL, int WPC, int INMODE>
-__global__ __launch_bounds__(WPC * 64) void lif_dense_kernel(const DenseArgs a)
+__global__ __launch_bounds__(WPC * 64) LSM_DENSE_VGPR_ATTR void lif_dense_kernel(const DenseArgs a)
 {
     constexpr bool INREG = INMODE == 1;
     constexpr bool INMASK = INMODE == 2;
@@ -76,7 +87,11 @@ __global__ __launch_bounds__(WPC * 64) void lif_dense_kernel(const DenseArgs a)
     constexpr int NPAD = NPW * WPC;
     constexpr int NT = WPC * 64;
     constexpr int R = 64 / WPC;            // fixed-region list entries per producer wave
-    constexpr int G = SL == 1 ? 16 : 32 / SL;   // rows in flight per group (<= 32 registers of weights)
+#ifndef LSM_DENSE_G4
+#define LSM_DENSE_G4 8
+#endif
+    // rows in flight per group (<= 32 registers of weights; LSM_DENSE_G4: the SL = 4 value, see LSM_DENSE_MAX_VGPR's note)
+    constexpr int G = SL == 1 ? 16 : (SL == 4 ? LSM_DENSE_G4 : 32 / SL);
     constexpr bool FEATREG = SL <= 4;           // feature accumulators in registers (4 per neuron) instead of LDS
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
