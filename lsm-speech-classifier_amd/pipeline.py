@@ -46,8 +46,9 @@ def configure_hardware_queues(n: int = DEFAULT_HW_QUEUES) -> int:
 
 
 class HotPath:
-    """fe: frontend.SpikeFrontEnd, net: snn.SNN (same device).  `streams` = depth of the rotation
-    (1 = serial: everything on the current stream)."""
+    """fe: frontend.SpikeFrontEnd, net: snn.SNN (same device).  `streams` = reservoir streams (1 = serial:
+    everything on the current stream); `fe_streams` = front-end streams of their own (0 = rotation: a step keeps to
+    one of the `streams`; None = DEFAULT_FE_STREAMS)."""
 
     def __init__(self, fe, net, feature_keys=None, streams: int = DEFAULT_STREAMS,
                  waves_per_clip: int | None = None, time_reservoir: bool = False,
@@ -82,18 +83,18 @@ class HotPath:
         self.wide_when_idle = os.environ.get("LSM_FE_WIDE_WHEN_IDLE", "1") != "0"
         self._wide_below = int(os.environ.get("LSM_FE_WIDE_BELOW", "1"))     # diagnostic: front ends in flight below which the wide layout goes out
         self._fe_done = []                  # events of the front ends issued, newest last (two-stage topology)
-        # Back-pressure: the host enqueues a step in ~60 us, the GPU runs it in ~640: without a bound a long run is
-        # enqueued thousands of steps ahead, and every step's raster (handed from its front-end stream to its reservoir
-        # stream, so the allocator may only reuse it once the reservoir launch has FINISHED) stays reserved until then:
-        # 13 MB x steps in flight (measured: 12 GB after 3000 steps).  submit() therefore waits for step s - max_ahead
-        # before it issues step s; the GPU keeps max_ahead steps queued, which is far more than it overlaps.
+        # Back-pressure: the host enqueues a step in ~0.1 ms, the GPU runs it in ~0.64: without a bound a long run is
+        # enqueued thousands of steps ahead and everything a step allocates stays reserved until the GPU gets there
+        # (measured before the pipeline owned its raster buffers: 12 GB after 3000 steps).  submit() therefore waits
+        # for step s - max_ahead before it issues step s; the GPU keeps max_ahead steps queued, far more than it overlaps.
         self.max_ahead = max(16, 4 * (self.n_streams + self.n_fe_streams))
         # Two-stage topology: the rasters and the front end's scratch live in buffers the pipeline owns, RASTER_DEPTH
         # rasters and one scratch per front-end stream, handed round behind events -- a raster buffer is written again
         # only after the reservoir launch that read it has finished (a GPU-side wait of the front-end stream, never
-        # a host wait).  Allocating them per step from torch's allocator would need the block of step s to stay
-        # reserved until its reservoir launch has finished on ANOTHER stream (`record_stream`), so a burst of steps
-        # enqueued ahead of the GPU calls hipMalloc inside the burst -- and hipMalloc stalls every queue.
+        # a host wait).  Allocating them per step from torch's allocator needs the block of step s to stay reserved
+        # until its reservoir launch has finished on ANOTHER stream (`record_stream`): memory then grows with the
+        # steps enqueued ahead and a burst allocates inside the timed path.  Throughput is the same either way
+        # (profiles/r03_pipeline_buffer_pool.txt); the pool makes the steady path free of allocator calls.
         self.pool = os.environ.get("LSM_HOTPATH_POOL", "1") != "0"
         self._rasters = {}                  # (front-end slot, batch size) -> [buffers], [events "free again"], next index
         self._ws = {}                       # (front-end slot, batch size) -> scratch

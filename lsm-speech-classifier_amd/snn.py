@@ -144,13 +144,14 @@ class SNN:
     KERNEL_MODES = {"auto": 0, "sparse": 1, "dense": 2, "ring": 3, "band": 3, "ring-contiguous": 4}
 
     def set_kernel(self, mode: str = "auto"):
+        """'auto' (register accumulation over dense presynaptic rows; over ring rows -- dense ring window
+        plus a list of the rewired synapses -- for ring-like reservoirs whose dense table exceeds the L2
+        caches), 'sparse' (CSC scatter through LDS), 'dense' or 'ring'.  'dense' on a reservoir that 'auto' serves
+        with ring rows builds the dense table now (one allocation + synchronisation on this device)."""
         with torch.cuda.device(self.device):
             return self._set_kernel(mode)
 
     def _set_kernel(self, mode: str = "auto"):
-        """'auto' (register accumulation over dense presynaptic rows; over ring rows -- dense ring window
-        plus a list of the rewired synapses -- for ring-like reservoirs whose dense table exceeds the L2
-        caches), 'sparse' (CSC scatter through LDS), 'dense' or 'ring'."""
         _lib.check(self.lib.lsm_reservoir_set_kernel(self._handle, self.KERNEL_MODES[mode]),
                    "lsm_reservoir_set_kernel")
 
