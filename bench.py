@@ -83,6 +83,10 @@ def parse_args(argv=None):
                     help="HIP streams the steps rotate over (0 = the pipeline's default; 1 = serial)")
     ap.add_argument("--fe-streams", type=int, default=None,
                     help="front-end streams of their own (0 = rotation: a step keeps to one stream; default: the pipeline's)")
+    ap.add_argument("--prime-ms", type=float, default=40.0,
+                    help="set-up, before the W warm-up steps: HotPath.prime() keeps the pipeline running untimed for this "
+                         "long so that the timed steps see the clock a running pipeline holds, not the ramp after an idle "
+                         "set-up phase (0 = one step per stream only)")
     ap.add_argument("--exchange", default="once", choices=["once", "per-step"],
                     help="N > 1: 'once' = every rank keeps its steps' feature rows and ONE all-gather follows the "
                          "last step, inside the timed region (what the product does: one gather per split, "
@@ -337,7 +341,8 @@ def run_rank(args):
             dist.barrier()
             torch.cuda.synchronize()
 
-    hp.prime(stage_in, stage=args.stage)   # set-up: every stream's allocator pool and first launch
+    # set-up: every stream's allocator pool and first launch, and the GPU's clock at its working point
+    primed_steps = hp.prime(stage_in, stage=args.stage, min_ms=args.prime_ms)
     hp.fork_from_current()             # inputs were produced on the default stream
     for i in range(args.warmup):
         out = step(i)
@@ -415,6 +420,8 @@ def run_rank(args):
                        "inputs": "pinned host memory, copied every step" if args.from_host else "resident in HBM",
                        "host_enqueue_ms_per_step": round(host_enqueue_ms, 4),
                        "streams": hp.n_streams, "fe_streams": hp.n_fe_streams, "hw_queues": hp.hw_queues,
+                       "prime": f"{primed_steps} untimed steps (>= {args.prime_ms:g} ms) in HotPath.prime() before the "
+                                f"{args.warmup} warm-up steps",
                        "pipeline": ("serial" if hp.n_streams <= 1 else
                                     "pipeline.HotPath: steps rotate over the streams" if not hp.n_fe_streams else
                                     "pipeline.HotPath: front ends on their own streams, reservoir launches behind events"),

@@ -224,19 +224,31 @@ class HotPath:
         buf.copy_(audio, non_blocking=True)
         return buf
 
-    def prime(self, audio, stage: str = "full"):
-        """One untimed step on EVERY stream of the rotation, then a synchronisation: each stream's first use
+    def prime(self, audio, stage: str = "full", min_ms: float = 0.0):
+        """One untimed step on EVERY stream of the pipeline, then a synchronisation: each stream's first use
         pays for its allocator pool (torch caches device memory per stream: the first `encode` on a stream
-        calls hipMalloc, which stalls every queue), for the first launch on its hardware queue and for the
-        kernels' one-off attribute calls.  Part of set-up; afterwards a step makes no runtime call but
-        launches and (host inputs) one asynchronous copy."""
+        calls hipMalloc, which stalls every queue), for the pipeline's own buffers, for the first launch on its
+        hardware queue and for the kernels' one-off attribute calls.  Part of set-up; afterwards a step makes no
+        runtime call but launches and (host inputs) one asynchronous copy.
+
+        `min_ms` > 0: keep submitting untimed steps until that much time has passed -- the GPU's clock governor
+        needs tens of milliseconds of load to reach the clock the pipeline then holds; a burst of steps that
+        starts right after a set-up phase (seconds of host work, an idle GPU) otherwise runs its first ~15 ms
+        6-9 % slower than the same steps in the middle of a long run (profiles/r03_clock_ramp.txt)."""
+        import time
         self.fork_from_current()
         events = self.reservoir_events
         self.reservoir_events = []
-        for _ in range(max(self.n_streams, self.n_fe_streams)):
+        t0 = time.perf_counter()
+        n = 0
+        while n < max(self.n_streams, self.n_fe_streams) or (time.perf_counter() - t0) * 1e3 < min_ms:
             self.submit(audio, stage=stage)
+            n += 1
+            if n % 8 == 0:                       # let the GPU catch up: the loop is timed by work done, not enqueued
+                self._in_flight and self._in_flight[-1].synchronize()
         self.synchronize()
         self.reservoir_events = events
+        return n
 
     def fork_from_current(self):
         """Make every stream of the rotation wait for what the current stream has issued so far
