@@ -49,7 +49,9 @@ int lsm_device_count(void);
  * nwin/hop are in samples (400/160 for the reference call), nwin <= 4*hop.
  * coef_flags (properties of the coefficient table the HOST has verified; 0 is always valid):
  *   bit 0  every A2 is exactly 0  -> the x*A2 products (signed zeros) are not evaluated
- *   bit 1  no gain has an all-ones significand -> y/gain through the exact Markstein FMA sequence */
+ *   bit 1  no gain has an all-ones significand -> y/gain through the exact Markstein FMA sequence
+ *   bit 2  A0/B0 is the same float64 for every channel (lsm_gammatone_spikes_f64 only: the product with the sample
+ *          is then formed once for the two channels a lane carries) */
 int lsm_gammatone_spec_f64(const float *audio, int n_clips, int n_samples, const double *coefs_dev,
                            int n_filters, int nwin, int hop, int ncols, double *spec_out,
                            double *db_out, int coef_flags, void *stream);

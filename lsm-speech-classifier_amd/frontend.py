@@ -66,7 +66,8 @@ def gammatone_filter_table(fs: float, channels: int, f_min: float) -> np.ndarray
 def coef_flags(tab: np.ndarray) -> int:
     """Properties of a coefficient table that let the kernel skip work without changing a bit:
     bit 0: every A2 is exactly zero; bit 1: no gain has an all-ones significand (the one case in
-    which the FMA division sequence is not guaranteed to round like a true division)."""
+    which the FMA division sequence is not guaranteed to round like a true division); bit 2: A0/B0 is the
+    same float64 for every channel (the fused kernel then forms b0*x once for the two channels of a lane)."""
     flags = 0
     if not np.any(tab[:, 5]):
         flags |= 1
@@ -74,6 +75,9 @@ def coef_flags(tab: np.ndarray) -> int:
     if np.all(np.isfinite(tab[:, 9])) and not np.any(mant == np.uint64((1 << 52) - 1)) \
             and np.all(np.abs(tab[:, 9]) > 1e-200) and np.all(np.abs(tab[:, 9]) < 1e200):
         flags |= 2
+    b0 = tab[:, 0] / tab[:, 6]
+    if np.all(np.isfinite(b0)) and np.all(b0.view(np.uint64) == b0[:1].view(np.uint64)):
+        flags |= 4
     return flags
 
 

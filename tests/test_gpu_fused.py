@@ -79,6 +79,28 @@ def test_fused_other_clip_lengths_and_window_overlaps(torch_cuda, oracle_c, n_sa
     np.testing.assert_array_equal(got.cpu().numpy(), ref)
 
 
+def test_fused_with_channel_dependent_first_section_gain(torch_cuda, oracle_c):
+    """coef_flags bit 2 (one A0/B0 for every channel: the product b0*x is shared by the two channels of a lane) is a
+    property the HOST verifies; a table without it takes the unshared kernel and still equals the oracle on that table."""
+    from lsm_speech_classifier_amd import frontend, synth
+    audio = synth.class_chirps([3, 8], seed=12)
+    fe = frontend.SpikeFrontEnd(128, "gammatone")
+    assert fe.coef_flags == 7
+    want = fe.encode(audio, fused=True)
+    tab = fe.coefs.cpu().numpy().copy()
+    tab[:, 0] *= 1.0 + 1e-3 * np.arange(128)                 # channel-dependent A0
+    fe.coefs = torch_cuda.from_numpy(tab).cuda()
+    fe.coef_flags = frontend.coef_flags(tab)
+    assert fe.coef_flags == 3
+    got = fe.encode(audio, fused=True)
+    assert torch_cuda.equal(got, fe.encode(audio, fused=False)) and not torch_cuda.equal(got, want)
+    ref = np.stack([oracle_c.encode_hysteresis(oracle_c.normalise_resize(oracle_c.gammatone_db(
+        oracle_c.gammatone_spec(a, tab, 400, 160, 98))), THR, GAP) for a in audio])
+    np.testing.assert_array_equal(got.cpu().numpy(), ref)
+    fe.coef_flags = 7                                        # lying about the table must change the result: the bit is used
+    assert not torch_cuda.equal(fe.encode(audio, fused=True), got)
+
+
 def test_fused_large_batch_equals_small_batches_and_split_path(torch_cuda):
     """cfg2's launch shape (256 clips x 128 filters: one wave per clip, CU-exclusive placement) and a launch
     that needs several workgroups per CU; batch position must not matter."""

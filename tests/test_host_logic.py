@@ -68,12 +68,15 @@ def test_gammatone_table_matches_oracle_restatement():
     for F in (2, 40, 128, 256):
         tab = frontend.gammatone_filter_table(16000, F, 50)
         np.testing.assert_array_equal(tab, O.gammatone_coefs(16000, F, 50))
-        assert frontend.coef_flags(tab) == 3
+        assert frontend.coef_flags(tab) == 7              # A2 == 0, divisible gains, one A0/B0 for every channel
         assert np.all(np.diff(tab[:, 7]) != 0)
     assert frontend.gtgram_strides(16000, 0.025, 0.01, 16000) == (400, 160, 98)
     bad = frontend.gammatone_filter_table(16000, 4, 50)
     bad[0, 5] = 1e-3
     assert frontend.coef_flags(bad) & 1 == 0
+    other = frontend.gammatone_filter_table(16000, 4, 50)
+    other[2, 0] *= 1.0 + 2.0 ** -40                          # one channel with its own first-section gain
+    assert frontend.coef_flags(other) == 3
 
 
 def test_threshold_tables_follow_the_reference_rounding():
