@@ -533,6 +533,10 @@ __global__ __launch_bounds__(GT_MAX_WPB * 64) void gammatone_spikes_kernel(const
             }
             return d / den;
         };
+#ifndef LSM_GTF_PASS_A_UNROLL
+#define LSM_GTF_PASS_A_UNROLL 1
+#endif
+#pragma unroll LSM_GTF_PASS_A_UNROLL
         for (int jw = 0; jw < BW; ++jw) {
             double x0[G][NCH], x1[G][NCH], w0[G], w1[G];
             bool two[G];
