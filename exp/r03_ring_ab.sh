@@ -1,6 +1,6 @@
 #!/bin/bash
-# Round 3: ring-row reservoir kernel with host-built row descriptors (scalar loads) against the previous build
-# (liblsm_hip_prev.so = commit 44afffd: seven v_readlane per row and wave, geometry recomputed per chunk), same box.
+# Round 3: ring-row reservoir kernel, new build against the previous commit (liblsm_hip_prev.so), same box.
+# (used for: row descriptors through scalar loads; three packed row words; fixed-pitch lists + early input counts)
 OUT=gpurun_out/r03_ring_ab.txt
 PREV=/root/repo/lsm-speech-classifier_amd/liblsm_hip_prev.so
 run() {
