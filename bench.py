@@ -416,6 +416,8 @@ def run_rank(args):
                        "small_world_k": cfg["k"], "num_output_neurons": cfg["n_out"],
                        "time_steps": fe.n_steps, "feature_set": "original",
                        "reservoir_kernel": net.kernel_in_use(),
+                       "reservoir_launch_order": ("longest clips first (lsm_reservoir_run_ordered)"
+                                                  if net.longest_first_default(B) else "batch order"),
                        "waves_per_clip": lay["waves_per_clip"], "lds_bytes_per_clip": lay["lds_bytes"],
                        "inputs": "pinned host memory, copied every step" if args.from_host else "resident in HBM",
                        "host_enqueue_ms_per_step": round(host_enqueue_ms, 4),

@@ -40,6 +40,9 @@ _SIGS = {
     "lsm_reservoir_kernel_in_use": (c_int, [c_void]),
     "lsm_reservoir_run": (c_int, [c_void, c_void, c_int, c_int, c_void, c_int, c_void, c_void,
                                   c_void, c_void, c_int, c_void]),
+    "lsm_reservoir_order_workspace": (C.c_long, [c_int]),
+    "lsm_reservoir_run_ordered": (c_int, [c_void, c_void, c_int, c_int, c_void, c_int, c_void, c_void,
+                                          c_void, c_void, c_int, c_void, C.c_long, c_void]),
     "lsm_reservoir_layout": (c_int, [c_void, c_int, c_int, c_int, C.POINTER(c_int),
                                      C.POINTER(c_int), C.POINTER(c_int)]),
     "lsm_reservoir_plan": (c_int, [c_void, c_int, c_int, c_int, C.POINTER(c_int), C.POINTER(c_int),

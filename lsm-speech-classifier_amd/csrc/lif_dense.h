@@ -58,6 +58,7 @@ struct DenseArgs {
     uint8_t *spike_matrix;     // (B, T, N) or null
     float *v_trace;            // (B, T, N) or null
     int32_t *stats;            // (B, 2) {neurons that fired at least once, spikes of the whole reservoir} or null
+    const int32_t *order;      // (B) clip of workgroup g, or null (g): lsm_reservoir_run_ordered starts long clips first
 };
 
 // INMODE: how the input drive m_i(t) = #{active channels feeding neuron i} is formed.
@@ -105,7 +106,7 @@ __global__ __launch_bounds__(WPC * 64) LSM_DENSE_VGPR_ATTR void lif_dense_kernel
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int b = blockIdx.x;
+    const int b = a.order ? a.order[blockIdx.x] : (int)blockIdx.x;      // wave-uniform
     const int N = a.N, T = a.T, CW = a.CW;
 
     // ---- prologue: zero LDS state, bit-pack the clip's raster time-major ----

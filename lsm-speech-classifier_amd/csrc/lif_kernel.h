@@ -77,6 +77,7 @@ struct LifArgs {
     uint8_t *spike_matrix;     // (B, T, N) or null
     float *v_trace;            // (B, T, N) or null
     int32_t *stats;            // (B, 2) {neurons that fired at least once, spikes of the whole reservoir} or null
+    const int32_t *order;      // (B) clip of workgroup g, or null (g): lsm_reservoir_run_ordered starts long clips first
 };
 
 __device__ __forceinline__ void wave_lds_fence()
@@ -117,7 +118,7 @@ __global__ __launch_bounds__(WPC * 64) void lif_kernel(const LifArgs a)
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int b = blockIdx.x;
+    const int b = a.order ? a.order[blockIdx.x] : (int)blockIdx.x;      // wave-uniform
     const int N = a.N, T = a.T, CW = a.CW;
 
     // ---- prologue: zero LDS state, stage tables, bit-pack the clip's raster time-major ----

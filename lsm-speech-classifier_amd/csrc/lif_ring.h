@@ -47,6 +47,15 @@ namespace lsm_lif {
 
 #define LSM_RING_ADD4(a, b) a = a + b;      // four floats: two v_pk_add_f32 (four v_add_f32 measured equal)
 
+#ifndef LSM_RING_PHASES
+#define LSM_RING_PHASES 0   // diagnostic builds only: 1 = every wave sums the core-clock cycles of its step phases and writes them
+#endif                      // OVER the feature rows (exp/r03_ring_phases.py reads them back); results are not features
+#if LSM_RING_PHASES         // (s_memtime returns through lgkmcnt: a mark also waits for the wave's outstanding LDS operations)
+#define LSM_RING_MARK(k) { const uint64_t now_ = __builtin_amdgcn_s_memtime(); ph_[k] += (uint32_t)(now_ - last_); last_ = now_; }
+#else
+#define LSM_RING_MARK(k)
+#endif
+
 #ifndef LSM_RING_ABLATE
 #define LSM_RING_ABLATE 0   // diagnostic builds only (1, 2, 8 give WRONG results): 1 = no window loads, 2 = no
 #endif                      // accumulator read-modify-write, 8 = no list loads
@@ -205,9 +214,34 @@ __global__ __launch_bounds__(WPC * 64) void lif_ring_kernel(const RingArgs a)
     const uint64_t band_base = reinterpret_cast<uint64_t>(a.band);
     const uint64_t rem_base = reinterpret_cast<uint64_t>(a.rem);
     const int H = a.H, NQ = a.NQ;
+#if LSM_RING_PHASES
+    uint32_t ph_[10] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};
+    uint32_t rows_ = 0u;
+    uint64_t last_ = 0;
+#endif
     uint32_t hf = 0u;                  // bit r: my neuron r fired at least once (stats)
     uint32_t tot_spk = 0u;             // spikes of my wave (stats)
     __syncthreads();
+
+    // !INREG: the wave's first XR*64 input-map entries are requested one step AHEAD -- after the rows of step t, before its
+    // update -- and consumed at the top of step t+1: their round trip hides behind the update and the barrier, and the
+    // registers that hold them are free again while the rows are applied.  Fetched inside input_drive they cost a step
+    // 3 700 cycles of exposed L2 latency at N = 4000 (23 % of it: profiles/r03_ring_phases.txt); kept in registers for
+    // good they cost the occupancy step at 128 registers.
+    constexpr int XR = 8;
+    uint32_t xp[XR];
+    auto fetch_entries = [&]() {
+        if (!INREG) {
+            uint32_t eo = (uint32_t)lane;
+            asm volatile("" : "+v"(eo));                                // not loop-invariant as far as the compiler can tell
+#pragma unroll
+            for (int u = 0; u < XR; ++u) {
+                const int e = u * 64 + (int)eo;
+                xp[u] = e < a.EinW ? my_ent[e] : 0xFFFFFFFFu;
+            }
+        }
+    };
+    fetch_entries();
 
     auto input_drive = [&](int ts) {
         const uint32_t *row = bits + ts * CW;
@@ -221,15 +255,8 @@ __global__ __launch_bounds__(WPC * 64) void lif_ring_kernel(const RingArgs a)
                 }
             }
         } else {
-            // eight entries per lane are fetched together (one L2 round trip per 512 entries instead of one per
-            // 64); a padding entry counts 0 into the lane's own dump word, so nothing is masked off
-            for (int e0 = 0; e0 < a.EinW; e0 += 512) {
-                uint32_t x[8];
-#pragma unroll
-                for (int u = 0; u < 8; ++u) {
-                    const int e = e0 + u * 64 + lane;
-                    x[u] = e < a.EinW ? my_ent[e] : 0xFFFFFFFFu;
-                }
+            // a padding entry counts 0 into the lane's own dump word, so nothing is masked off
+            auto drive8 = [&](const uint32_t *x, int e0) __attribute__((always_inline)) {
 #pragma unroll
                 for (int u = 0; u < 8; ++u) {
                     if (e0 + u * 64 < a.EinW) {                     // wave-uniform
@@ -241,6 +268,19 @@ __global__ __launch_bounds__(WPC * 64) void lif_ring_kernel(const RingArgs a)
                                   ok ? bit << ((i & 1u) * 16u) : 0u);
                     }
                 }
+            };
+#pragma unroll
+            for (int g = 0; g < XR / 8; ++g)
+                if (g * 512 < a.EinW) drive8(xp + 8 * g, g * 512);
+            // longer maps: eight entries per lane are fetched together (one L2 round trip per 512 entries)
+            for (int e0 = XR * 64; e0 < a.EinW; e0 += 512) {
+                uint32_t x[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int e = e0 + u * 64 + lane;
+                    x[u] = e < a.EinW ? my_ent[e] : 0xFFFFFFFFu;
+                }
+                drive8(x, e0);
             }
         }
     };
@@ -250,12 +290,21 @@ __global__ __launch_bounds__(WPC * 64) void lif_ring_kernel(const RingArgs a)
         const uint16_t *list_prev = wlist + prv * NPAD;
         uint16_t *list_cur = wlist + cur * NPAD;
 
+        // ---- this step's input counts, first: they touch only the count words of the wave's own neurons, which its update of
+        //      the last step cleared (program order), and the entries they need were requested before that update ----
+        input_drive(t);
+        LSM_RING_MARK(4)               // input counts
+
         // ---- spiking neurons of step t-1: prefix of the per-quad counts, lane l <- l-th neuron ----
         const uint32_t cv = wcnt[prv * 32 + (lane & 31)];
         uint32_t total = 0u;
 #pragma unroll
         for (int g = 0; g < NQP; ++g) total += __builtin_amdgcn_readlane(cv, g);
 
+        LSM_RING_MARK(0)               // quad counts read, total known
+#if LSM_RING_PHASES
+        rows_ += total;
+#endif
         for (uint32_t l0 = 0; l0 < total; l0 += 64) {
             const uint32_t l = l0 + lane;
             uint32_t gsel = 0u, pbase = 0u, run = 0u;      // (the prefix is formed again per chunk: it would
@@ -304,6 +353,10 @@ __global__ __launch_bounds__(WPC * 64) void lif_ring_kernel(const RingArgs a)
             const uint32_t p_a = (uint32_t)jl | ((p_nrec >> 4) << 16);
             const uint32_t p_c = r0 | ((r1 - r0) << 24);                // host: fewer than 2^24 list entries per layout
             const int n = (int)min(64u, total - l0);
+#if LSM_RING_PHASES
+            asm volatile("" : : "v"(p_a), "v"(p_c), "v"(p_soff));      // the row words (and the pointer loads) have arrived
+#endif
+            LSM_RING_MARK(1)           // chunk set-up: prefix, list read, geometry, list pointers
             ring_f4 wv[P][WL];
             ring_u2 re[P];
             ring_f4 old[WL];                     // accumulators under the window load of the row being applied
@@ -388,6 +441,7 @@ __global__ __launch_bounds__(WPC * 64) void lif_ring_kernel(const RingArgs a)
                 LSM_RING_LOADW(p, p)
                 LSM_RING_LOADL(p, p)
             }
+            LSM_RING_MARK(2)           // first P rows requested
             LSM_RING_READ(0)
             for (int m = 0; m < n; m += P) {
 #pragma unroll
@@ -398,12 +452,13 @@ __global__ __launch_bounds__(WPC * 64) void lif_ring_kernel(const RingArgs a)
                     LSM_RING_LOADL(p, m + p + P)
                 }
             }
+            LSM_RING_MARK(3)           // rows applied (waits for the row loads included)
 #undef LSM_RING_LOADW
 #undef LSM_RING_LOADL
 #undef LSM_RING_READ
 #undef LSM_RING_APPLY
         }
-        input_drive(t);
+        fetch_entries();               // the NEXT step's input-map entries: their round trip hides behind the update and the barrier
         wave_lds_fence();
 
         // ---- neuron update, quad by quad: leak/integrate/threshold by select, then (only if a neuron of the
@@ -479,7 +534,9 @@ __global__ __launch_bounds__(WPC * 64) void lif_ring_kernel(const RingArgs a)
             }
         }
         tot_spk += (uint32_t)nspk;
+        LSM_RING_MARK(5)               // neuron update, spike lists, feature accumulators
         __syncthreads();
+        LSM_RING_MARK(6)               // barrier
     }
 #undef LSM_RING_GQ
 
@@ -518,6 +575,13 @@ __global__ __launch_bounds__(WPC * 64) void lif_ring_kernel(const RingArgs a)
         }
         a.features[(size_t)b * nf + idx] = (float)val;
     }
+#if LSM_RING_PHASES
+    __syncthreads();
+    float out_ = (float)rows_;
+#pragma unroll
+    for (int k = 0; k < 10; ++k) out_ = lane == k ? (float)ph_[k] : out_;
+    if (lane < 11 && nf >= WPC * 16) a.features[(size_t)b * nf + w * 16 + lane] = out_;
+#endif
 }
 
 typedef void (*ring_fn_t)(const RingArgs);

@@ -10,6 +10,7 @@ in liblsm_hip.so; there is no CPU fallback.
 from __future__ import annotations
 
 import ctypes as C
+import os
 
 import numpy as np
 import torch
@@ -53,6 +54,7 @@ class SNN:
         self.n_channels = reservoir.n_channels
         self.num_output_neurons = len(reservoir.out_idx)
         self._handle = C.c_void_p()
+        self._compute_units = torch.cuda.get_device_properties(self.device).multi_processor_count
         r = reservoir
         with torch.cuda.device(self.device):
             _lib.check(self.lib.lsm_reservoir_create(
@@ -76,7 +78,8 @@ class SNN:
 
     # ---- batched path -------------------------------------------------------------------
     def run_batch(self, spikes, feature_keys=None, want_spike_matrix=False, want_v_trace=False,
-                  waves_per_clip: int = 0, packed_time_steps: int = 0, stats_out=None, features_out=None):
+                  waves_per_clip: int = 0, packed_time_steps: int = 0, stats_out=None, features_out=None,
+                  longest_first: bool | None = None):
         """spikes: uint8 (B, C, T) torch tensor on this device (or NumPy, copied).  Returns
         (features float32 (B, n_keys*N_out) device tensor, spike_matrix or None, v_trace or None);
         NaN entries are already 0 and keys are concatenated in the given order
@@ -87,7 +90,11 @@ class SNN:
         ``waves_per_clip``: 0 = the library's layout for a lone launch, -1 = its layout for a launch that
         shares the GPU with other kernels (``pipeline.HotPath``), else 1, 2, 4, 8 or 16.
         ``features_out``: optional contiguous float32 (B, n_keys*N_out) device tensor to write the rows into
-        (e.g. this step's slice of a gather buffer) instead of a fresh one."""
+        (e.g. this step's slice of a gather buffer) instead of a fresh one.
+        ``longest_first``: start the clips with the most input spikes first (``lsm_reservoir_run_ordered``: a
+        clip's time grows with its activity, and a launch of several rounds is otherwise as long as whichever
+        clip starts last); results are the same either way.  Default: on when the batch has more clips than the
+        GPU has compute units (``LSM_RESERVOIR_ORDER=0`` turns the default off)."""
         if isinstance(spikes, np.ndarray):
             spikes = torch.from_numpy(np.ascontiguousarray(spikes, dtype=np.uint8))
         spikes = spikes.to(self.device, dtype=torch.uint8).contiguous()
@@ -116,12 +123,28 @@ class SNN:
         if stats_out is not None and (stats_out.dtype != torch.int32 or tuple(stats_out.shape) != (B, 2)
                                       or not stats_out.is_contiguous() or stats_out.device != spikes.device):
             raise ValueError(f"stats_out must be a contiguous int32 ({B}, 2) tensor on {spikes.device}")
+        if longest_first is None:
+            longest_first = self.longest_first_default(B)
         with torch.cuda.device(self.device):
-            _lib.check(self.lib.lsm_reservoir_run(
-                self._handle, _dev(spikes), B, T, _host(key_ids), len(keys), _dev(feats), _dev(sm),
-                _dev(vt), _dev(stats_out), int(waves_per_clip), torch.cuda.current_stream(self.device).cuda_stream),
-                "lsm_reservoir_run")
+            stream = torch.cuda.current_stream(self.device).cuda_stream
+            if longest_first:
+                # scratch of this call alone: the caching allocator hands a block back to the stream it was taken on
+                need = self.lib.lsm_reservoir_order_workspace(B)
+                ws = torch.empty((need + 3) // 4, dtype=torch.int32, device=self.device)
+                _lib.check(self.lib.lsm_reservoir_run_ordered(
+                    self._handle, _dev(spikes), B, T, _host(key_ids), len(keys), _dev(feats), _dev(sm),
+                    _dev(vt), _dev(stats_out), int(waves_per_clip), _dev(ws), need, stream),
+                    "lsm_reservoir_run_ordered")
+            else:
+                _lib.check(self.lib.lsm_reservoir_run(
+                    self._handle, _dev(spikes), B, T, _host(key_ids), len(keys), _dev(feats), _dev(sm),
+                    _dev(vt), _dev(stats_out), int(waves_per_clip), stream),
+                    "lsm_reservoir_run")
         return feats, sm, vt
+
+    def longest_first_default(self, n_clips: int) -> bool:
+        """Whether ``run_batch`` starts the clips of a batch of this size longest first by default."""
+        return n_clips > self._compute_units and os.environ.get("LSM_RESERVOIR_ORDER", "1") != "0"
 
     def diagnostics(self, spikes) -> dict:
         """Batched health statistics (the quantities /root/reference/extract_lsm_features.py:119-133
