@@ -49,8 +49,10 @@ namespace lsm_lif {
 
 #ifndef LSM_RING_PHASES
 #define LSM_RING_PHASES 0   // diagnostic builds only: 1 = every wave sums the core-clock cycles of its step phases and writes them
-#endif                      // OVER the feature rows (exp/r03_ring_phases.py reads them back); results are not features
-#if LSM_RING_PHASES         // (s_memtime returns through lgkmcnt: a mark also waits for the wave's outstanding LDS operations)
+#endif                      // OVER the feature rows (exp/r03_ring_phases.py reads them back); results are not features.
+#if LSM_RING_PHASES         // A mark is not free: s_memtime returns through lgkmcnt (it waits for the wave's outstanding LDS
+                            // operations) and the compiler moves no memory operation across it -- phases that the product build
+                            // overlaps (e.g. the input-map fetch with the last rows) show up serialised here.
 #define LSM_RING_MARK(k) { const uint64_t now_ = __builtin_amdgcn_s_memtime(); ph_[k] += (uint32_t)(now_ - last_); last_ = now_; }
 #else
 #define LSM_RING_MARK(k)
@@ -80,6 +82,7 @@ struct RingArgs {
     uint8_t *spike_matrix;     // (B, T, N) or null
     float *v_trace;            // (B, T, N) or null
     int32_t *stats;            // (B, 2) {neurons that fired at least once, spikes of the whole reservoir} or null
+    const int32_t *order;      // (B) clip of workgroup g, or null (g): lsm_reservoir_run_ordered starts long clips first
 };
 
 typedef float ring_f4 __attribute__((ext_vector_type(4)));
@@ -130,7 +133,7 @@ __global__ __launch_bounds__(WPC * 64) void lif_ring_kernel(const RingArgs a)
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int b = blockIdx.x;
+    const int b = a.order ? a.order[blockIdx.x] : (int)blockIdx.x;      // wave-uniform
     const int N = a.N, T = a.T, CW = a.CW;
     // global quad of my register quad q
 #define LSM_RING_GQ(q) (STRIDED ? (q) * WPC + w : w * QL + (q))
@@ -215,33 +218,13 @@ __global__ __launch_bounds__(WPC * 64) void lif_ring_kernel(const RingArgs a)
     const uint64_t rem_base = reinterpret_cast<uint64_t>(a.rem);
     const int H = a.H, NQ = a.NQ;
 #if LSM_RING_PHASES
-    uint32_t ph_[10] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};
+    uint32_t ph_[8] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};
     uint32_t rows_ = 0u;
     uint64_t last_ = 0;
 #endif
     uint32_t hf = 0u;                  // bit r: my neuron r fired at least once (stats)
     uint32_t tot_spk = 0u;             // spikes of my wave (stats)
     __syncthreads();
-
-    // !INREG: the wave's first XR*64 input-map entries are requested one step AHEAD -- after the rows of step t, before its
-    // update -- and consumed at the top of step t+1: their round trip hides behind the update and the barrier, and the
-    // registers that hold them are free again while the rows are applied.  Fetched inside input_drive they cost a step
-    // 3 700 cycles of exposed L2 latency at N = 4000 (23 % of it: profiles/r03_ring_phases.txt); kept in registers for
-    // good they cost the occupancy step at 128 registers.
-    constexpr int XR = 8;
-    uint32_t xp[XR];
-    auto fetch_entries = [&]() {
-        if (!INREG) {
-            uint32_t eo = (uint32_t)lane;
-            asm volatile("" : "+v"(eo));                                // not loop-invariant as far as the compiler can tell
-#pragma unroll
-            for (int u = 0; u < XR; ++u) {
-                const int e = u * 64 + (int)eo;
-                xp[u] = e < a.EinW ? my_ent[e] : 0xFFFFFFFFu;
-            }
-        }
-    };
-    fetch_entries();
 
     auto input_drive = [&](int ts) {
         const uint32_t *row = bits + ts * CW;
@@ -255,8 +238,15 @@ __global__ __launch_bounds__(WPC * 64) void lif_ring_kernel(const RingArgs a)
                 }
             }
         } else {
-            // a padding entry counts 0 into the lane's own dump word, so nothing is masked off
-            auto drive8 = [&](const uint32_t *x, int e0) __attribute__((always_inline)) {
+            // eight entries per lane are fetched together (one L2 round trip per 512 entries instead of one per
+            // 64); a padding entry counts 0 into the lane's own dump word, so nothing is masked off
+            for (int e0 = 0; e0 < a.EinW; e0 += 512) {
+                uint32_t x[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int e = e0 + u * 64 + lane;
+                    x[u] = e < a.EinW ? my_ent[e] : 0xFFFFFFFFu;
+                }
 #pragma unroll
                 for (int u = 0; u < 8; ++u) {
                     if (e0 + u * 64 < a.EinW) {                     // wave-uniform
@@ -268,32 +258,17 @@ __global__ __launch_bounds__(WPC * 64) void lif_ring_kernel(const RingArgs a)
                                   ok ? bit << ((i & 1u) * 16u) : 0u);
                     }
                 }
-            };
-#pragma unroll
-            for (int g = 0; g < XR / 8; ++g)
-                if (g * 512 < a.EinW) drive8(xp + 8 * g, g * 512);
-            // longer maps: eight entries per lane are fetched together (one L2 round trip per 512 entries)
-            for (int e0 = XR * 64; e0 < a.EinW; e0 += 512) {
-                uint32_t x[8];
-#pragma unroll
-                for (int u = 0; u < 8; ++u) {
-                    const int e = e0 + u * 64 + lane;
-                    x[u] = e < a.EinW ? my_ent[e] : 0xFFFFFFFFu;
-                }
-                drive8(x, e0);
             }
         }
     };
 
+#if LSM_RING_PHASES
+    last_ = __builtin_amdgcn_s_memtime();
+#endif
     for (int t = 0; t < T; ++t) {
         const int cur = t & 1, prv = cur ^ 1;
         const uint16_t *list_prev = wlist + prv * NPAD;
         uint16_t *list_cur = wlist + cur * NPAD;
-
-        // ---- this step's input counts, first: they touch only the count words of the wave's own neurons, which its update of
-        //      the last step cleared (program order), and the entries they need were requested before that update ----
-        input_drive(t);
-        LSM_RING_MARK(4)               // input counts
 
         // ---- spiking neurons of step t-1: prefix of the per-quad counts, lane l <- l-th neuron ----
         const uint32_t cv = wcnt[prv * 32 + (lane & 31)];
@@ -458,8 +433,9 @@ __global__ __launch_bounds__(WPC * 64) void lif_ring_kernel(const RingArgs a)
 #undef LSM_RING_READ
 #undef LSM_RING_APPLY
         }
-        fetch_entries();               // the NEXT step's input-map entries: their round trip hides behind the update and the barrier
+        input_drive(t);
         wave_lds_fence();
+        LSM_RING_MARK(4)               // input counts (the fetch of the input-map entries included)
 
         // ---- neuron update, quad by quad: leak/integrate/threshold by select, then (only if a neuron of the
         //      quad fired) its entries of the quad's spike list and the feature accumulators ----
@@ -579,8 +555,8 @@ __global__ __launch_bounds__(WPC * 64) void lif_ring_kernel(const RingArgs a)
     __syncthreads();
     float out_ = (float)rows_;
 #pragma unroll
-    for (int k = 0; k < 10; ++k) out_ = lane == k ? (float)ph_[k] : out_;
-    if (lane < 11 && nf >= WPC * 16) a.features[(size_t)b * nf + w * 16 + lane] = out_;
+    for (int k = 0; k < 7; ++k) out_ = lane == k ? (float)ph_[k] : out_;
+    if (lane < 8 && nf >= WPC * 8) a.features[(size_t)b * nf + w * 8 + lane] = out_;
 #endif
 }
 
