@@ -61,6 +61,8 @@ def main():
     per_cu = max(1, min(160 * 1024 // lds, 32 // wpc))
     slots = per_cu * torch.cuda.get_device_properties(0).multi_processor_count
     keys = rasters.reshape(B, -1).sum(dim=1).cpu().numpy()
+    os.makedirs("gpurun_out", exist_ok=True)
+    np.save(f"gpurun_out/r03_clip_cycles_{name}_B{B}.npy", np.stack([keys.astype(np.float64), slow.astype(np.float64)]))
     lpt = np.argsort(-keys, kind="stable")
     ideal = np.argsort(-slow, kind="stable")
     tot = slow.sum() / slots

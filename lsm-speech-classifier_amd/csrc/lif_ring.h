@@ -570,7 +570,7 @@ ring_fn_t pick_ring_wpc(int wpc)
     case 4: return lif_ring_kernel<QL, 4, INREG, STRIDED>;
     case 8: return lif_ring_kernel<QL, 8, INREG, STRIDED>;
     case 16:
-        if constexpr (QL < 4) return lif_ring_kernel<QL, 16, INREG, STRIDED>;     // N <= 8192 = 16 waves x 2 quads
+        if constexpr (QL * 16 <= RING_MAX_QUADS) return lif_ring_kernel<QL, 16, INREG, STRIDED>;   // N <= 8192 = 16 waves x 2 quads
         else return nullptr;
     default: return nullptr;
     }
@@ -586,6 +586,7 @@ ring_fn_t pick_ring(int wpc, bool inreg, bool strided)
 // one definition per translation unit lif_ring_<ql>.hip
 ring_fn_t pick_ring_1(int wpc, bool inreg, bool strided);
 ring_fn_t pick_ring_2(int wpc, bool inreg, bool strided);
+ring_fn_t pick_ring_3(int wpc, bool inreg, bool strided);
 ring_fn_t pick_ring_4(int wpc, bool inreg, bool strided);
 
 }  // namespace lsm_lif

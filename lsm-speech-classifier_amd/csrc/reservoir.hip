@@ -356,9 +356,9 @@ int lsm_reservoir_create(lsm_reservoir **out, int num_neurons, int n_channels,
                         // ring's wrap (NQ % wpc == 0) and a window must not be wider than wpc quads
                         if (NQ % wpc != 0 || wsq > wpc) continue;
                         ql = NQ / wpc;
-                        if (ql != 1 && ql != 2 && ql != 4) continue;
+                        if (ql < 1 || ql > 4) continue;
                     } else {
-                        for (int cand : {1, 2, 4})
+                        for (int cand : {1, 2, 3, 4})
                             if (!ql && wpc * cand * 256 >= N) ql = cand;
                         // a wave must never hold both ends of a (wrapped) window: window quads + QL <= NQ
                         if (!ql || wsq + ql > NQ) continue;
@@ -693,6 +693,7 @@ static int reservoir_run(const lsm_reservoir *h, const uint8_t *spikes_u8, int n
         const bool inreg = rv->einw <= IN_REG_SLOTS * 64;
         lsm_lif::ring_fn_t rfn = rv->ql == 1   ? lsm_lif::pick_ring_1(rv->wpc, inreg, rv->strided)
                                  : rv->ql == 2 ? lsm_lif::pick_ring_2(rv->wpc, inreg, rv->strided)
+                                 : rv->ql == 3 ? lsm_lif::pick_ring_3(rv->wpc, inreg, rv->strided)
                                                : lsm_lif::pick_ring_4(rv->wpc, inreg, rv->strided);
         LSM_REQUIRE(rfn != nullptr, "no ring kernel for QL=%d WPC=%d", rv->ql, rv->wpc);
         lsm_lif::RingArgs r;

@@ -126,3 +126,59 @@ def test_small_batches_are_launched_as_they_are_and_errors(torch_cuda):
     # an empty batch is fine without a workspace, like lsm_reservoir_run
     assert lib.lsm_reservoir_run_ordered(net._handle, None, 0, t, kid.ctypes.data, 1, None, None, None, None, 0,
                                          None, 0, stream) == 0
+
+
+def test_ordered_launch_captures_into_a_hip_graph(torch_cuda):
+    """Counting, ranking and the LIF launch are three launches on the caller's stream and nothing else (no allocation,
+    no synchronisation): captured once, replayed on another batch, equal to the eager launches."""
+    torch = torch_cuda
+    cus = torch.cuda.get_device_properties(0).multi_processor_count
+    n, c, t = cus + 11, 16, 48
+    r0, r1 = _uneven_rasters(n, c, t, seed=21), _uneven_rasters(n, c, t, seed=22)
+    res, net = _net(512, 100, c, r0)
+    d0, d1 = torch.from_numpy(r0).cuda(), torch.from_numpy(r1).cuda()
+    e0, _, _ = net.run_batch(d0, KEYS, longest_first=True)           # first use of every kernel
+    e1, _, _ = net.run_batch(d1, KEYS, longest_first=False)
+    torch.cuda.synchronize()
+    static_in = d0.clone()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        feats, _, _ = net.run_batch(static_in, KEYS, longest_first=True)
+    g.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(feats, e0)
+    static_in.copy_(d1)
+    g.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(feats, e1) and not torch.equal(e0, e1)
+
+
+@pytest.mark.parametrize("n,k,want_wpc", [(3072, 614, 4), (1536, 100, 2)])
+def test_ring_rows_with_three_quads_per_wave(torch_cuda, oracle_c, n, k, want_wpc):
+    """Reservoirs whose quad count is a multiple of three (N = 3072: 12 quads) had no strided ring layout:
+    with three quads per wave they do (4 waves x 3 quads; the window's <= 4 quads fall into different waves).  Bit-exact
+    against the oracle, spike matrix and membrane trace included, and against the contiguous layouts and the dense rows."""
+    torch = torch_cuda
+    from lsm_speech_classifier_amd import reservoir as R, snn, synth
+    from oracle import ref_numpy as O
+    c, t, b = 32, 50, 6
+    rasters = synth.bernoulli_raster(b, c, t, 0.25, seed=n)
+    wc = O.w_critico(k, 2.0, 2, rasters)
+    res = R.build_reservoir(R.SimulationParams(num_neurons=n, num_output_neurons=n // 3, small_world_graph_k=k,
+                                               mean_weight=wc * 1.3), c)
+    net = snn.SNN(None, reservoir=res)
+    net.set_kernel("ring")
+    plan = net.plan(b, t, 0)
+    assert plan["kernel"] == "ring" and plan["waves_per_clip"] == want_wpc and plan["slots_per_lane"] == 12
+    feats, sm, vt = net.run_batch(rasters, KEYS, want_spike_matrix=True, want_v_trace=True)
+    for i in range(b):
+        f_ref, sm_ref, vt_ref = oracle_c.lif_run(res, rasters[i], KEYS, want_trace=True)
+        np.testing.assert_array_equal(feats[i].cpu().numpy(), f_ref)
+        np.testing.assert_array_equal(sm[i].cpu().numpy(), sm_ref)
+        np.testing.assert_array_equal(vt[i].cpu().numpy().view(np.uint32), vt_ref.view(np.uint32))
+    assert sm.sum() > 0
+    net.set_kernel("ring-contiguous")
+    f_cont, _, _ = net.run_batch(rasters, KEYS)
+    net.set_kernel("dense")
+    f_dense, _, _ = net.run_batch(rasters, KEYS)
+    assert torch.equal(feats, f_cont) and torch.equal(feats, f_dense)
