@@ -107,6 +107,21 @@ int main(void)
     if (lsm_reservoir_run(h, d_r, B, T, &bad, 1, d_f, NULL, NULL, NULL, 0, st) == 0 || !lsm_last_error()[0]) { printf("FAIL bad key accepted\n"); return 1; }
     CHECK(lsm_reservoir_run(h, d_r, B, T, keys, 8, d_f, NULL, NULL, NULL, 0, st));
     HIP(hipStreamSynchronize(st));
+    /* the same batch through the entry point that starts long clips first (caller-owned workspace): same rows */
+    {
+        void *ws = NULL;
+        const long need = lsm_reservoir_order_workspace(B);
+        if (need != 8L * B) { printf("FAIL workspace size %ld\n", need); return 1; }
+        HIP(hipMalloc(&ws, (size_t)need));
+        HIP(hipMemset(d_f, 0xff, B * nf * sizeof(float)));
+        CHECK(lsm_reservoir_run_ordered(h, d_r, B, T, keys, 8, d_f, NULL, NULL, NULL, 0, ws, need, st));
+        HIP(hipStreamSynchronize(st));
+        static float again[B][8 * NOUT];
+        HIP(hipMemcpy(again, d_f, sizeof(again), hipMemcpyDeviceToHost));
+        if (memcmp(again, got, sizeof(got)) != 0) { printf("FAIL ordered launch differs\n"); return 1; }
+        if (lsm_reservoir_run_ordered(h, d_r, B, T, keys, 8, d_f, NULL, NULL, NULL, 0, ws, need - 1, st) == 0) { printf("FAIL short workspace accepted\n"); return 1; }
+        HIP(hipFree(ws));
+    }
     CHECK(lsm_reservoir_destroy(h));
     if (spikes == 0) { printf("FAIL reservoir never fired\n"); return 1; }
     printf("C ABI OK: version %d, %ld output spikes, features bit-identical to the oracle for 3 layouts\n", lsm_version(), spikes / 3);
