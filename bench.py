@@ -464,6 +464,11 @@ def run_rank(args):
                 "compulsory_bytes_per_clip": round(compulsory, 1),
                 "compulsory_gbs": round(compulsory * B / (lif_ms * 1e-3) / 1e9, 3),
                 "kernel_clips_per_s": round(B / (lif_ms * 1e-3), 1),
+                # the same algorithmic bytes against the WALL CLOCK of the path: one launch's bytes are consumed per step,
+                # however many launches overlap (kernel_ms / ms_per_step of them are in flight on average)
+                "launches_in_flight": round(lif_ms / ms_step, 2),
+                "pipeline_gbs": round(per_clip * B / (ms_step * 1e-3) / 1e9, 2),
+                "pipeline_frac": round(per_clip * B / (ms_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
                 "note": "kernel_ms is the HIP-event average over the timed region, where launches of "
                         "consecutive steps overlap on the GPU; idle_gpu_* is the same launch (same layout) alone; "
                         "lone_launch_* is a lone launch in the layout the library picks for it",

@@ -51,6 +51,10 @@ def test_bench_line_names_the_committed_traffic_file_at_the_headline_shape():
     assert r["traffic"] > 0 and "profiles/lif_traffic.json[cfg2_B256_dense]" in r["traffic_source"]
     assert "not measured in this run" in r["traffic_source"]
     assert 0 < r["memory_side_frac"] < 1 and r["memory_side_gbs_lone_launch"] > 0
+    # the launch's algorithmic bytes against the wall clock of the path, beside the per-launch figure of the contract
+    assert abs(r["launches_in_flight"] - r["kernel_ms"] / d["ms_per_step"]) < 0.02 and r["launches_in_flight"] > 1
+    assert abs(r["pipeline_frac"] - r["frac"] * r["launches_in_flight"]) < 0.01 * r["pipeline_frac"] + 1e-4
+    assert d["config"]["reservoir_launch_order"] == "batch order"          # 256 clips: one per compute unit
     assert d["config"]["hw_queues"] == 12 and d["config"]["streams"] == 6 and d["config"]["fe_streams"] == 5
 
 
