@@ -8,6 +8,7 @@ import os
 from . import build as _build
 
 _lib = None
+ABI_VERSION = 400          # lsm_version() of the library this binding was written against (0.4.0 = __version__)
 
 c_void = C.c_void_p
 c_int = C.c_int
@@ -72,6 +73,15 @@ def load():
             f"{path} not found: the HIP extension is not built. Run `python -c \"import "
             f"__graft_entry__ as g; g.build()\"` (needs hipcc). There is no CPU fallback.")
     lib = C.CDLL(path)
+    try:
+        lib.lsm_version.restype = c_int
+        have = int(lib.lsm_version())
+    except AttributeError:
+        have = -1
+    if have != ABI_VERSION:              # a stale .so: say so instead of failing on the first new symbol
+        raise LsmHipError(
+            f"{path} reports ABI version {have}, this package needs {ABI_VERSION}: rebuild the extension "
+            f"(`python -c \"import __graft_entry__ as g; g.build()\"`).")
     for name, (res, args) in _SIGS.items():
         fn = getattr(lib, name)          # AttributeError here = header/library mismatch
         fn.restype = res

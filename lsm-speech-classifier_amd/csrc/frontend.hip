@@ -509,7 +509,7 @@ __global__ __launch_bounds__(GT_MAX_WPB * 64) void gammatone_spikes_kernel(const
     // Pass A (no dependency between bins, the loads of a whole group of bins in flight together): per bin j and
     // threshold t the two comparisons the latch needs, S = val > on[t] in bit t and R = val < off[t] in bit FBH + t
     // of the bin's field; JPW fields per LDS word of the lane's row.  Pass B (serial in j, LDS only) runs the
-    // set/reset latches of all thresholds at once, A = S | (A & ~R), and packs the raster bits IN PLACE: the
+    // set/reset latches of all thresholds at once, A = (S & ~A) | (A & ~R), and packs the raster bits IN PLACE: the
     // raster word of bin j lies at or below the field word of bin j in the same row.  Fields of bins >= Tb in the
     // last word repeat the last bin and are never read.
     const int FBH = n_thr <= 4 ? 4 : 8;                 // bits per half field
@@ -615,7 +615,9 @@ __global__ __launch_bounds__(GT_MAX_WPB * 64) void gammatone_spikes_kernel(const
             if (u == 0) cur = srow[j / JPW];
             const uint32_t field = cur >> (u * 2 * FBH);
             const uint32_t S = field & tmask, R = (field >> FBH) & tmask;
-            act = S | (act & ~R);
+            // create_dataset.py:90-95: rising and falling are both taken from the latch BEFORE the update, so an
+            // active latch with S and R both true (only possible when off > on: a negative gap) is cleared
+            act = (S & ~act) | (act & ~R);
             acc |= (unsigned long long)act << fill;
             fill += n_thr;
             if (fill >= 32) {
@@ -883,6 +885,9 @@ static bool fused_plan(int n_filters, int launch_flags, FusedPlan *p)
     static const int nch_env = [] { const char *e = getenv("LSM_GTF_NCH"); return e ? atoi(e) : 0; }();
     if (nch_env == 1 || nch_env == 2) nch = nch_env;
 #endif
+    // the low-latency flag is a layout hint, never a reason to refuse: 513..1024 filters need more than GT_MAX_WPB
+    // one-chain waves per clip, so they keep the two-chain layout whatever the flag says
+    if (nch == 1 && (n_filters + 63) / 64 > GT_MAX_WPB) nch = 2;
     const int groups = (n_filters + 64 * nch - 1) / (64 * nch);
     if (groups > GT_MAX_WPB) return false;
     int wpb = groups >= 4 ? groups : groups * (4 / groups);     // a multiple of `groups`, about 4 waves

@@ -30,7 +30,8 @@ void lsm_allow_big_lds(const void *kernel_fn)
 
 #define LSM_API extern "C" __attribute__((visibility("default")))
 
-LSM_API int lsm_version(void) { return 200; }   // 0.2.0: ring-row reservoir kernel, stats_out, lsm_reservoir_kernel_in_use
+// major*10000 + minor*100 + patch; in step with the package's __version__ and _lib.ABI_VERSION (which refuses another number)
+LSM_API int lsm_version(void) { return 400; }   // 0.4.0
 
 LSM_API const char *lsm_last_error(void) { return g_err; }
 

@@ -168,6 +168,13 @@ class SpikeFrontEnd:
             return 0
         return max(int(self.lib.lsm_gammatone_spikes_workspace(int(n_clips), self.n_filters, self.ncols)), 8) // 8
 
+    def will_fuse(self) -> bool:
+        """Whether `encode()` takes the one-launch route by default.  ONE decision for `encode()` and for
+        `pipeline.HotPath`, which hands its own raster buffers to the fused launch only.
+        LSM_FRONTEND_SPLIT=1: diagnostic switch for same-box A/B runs of the two routes (exp/r03_fused_sweep.sh)."""
+        return (self.filterbank == "gammatone" and self.n_filters <= 1024
+                and os.environ.get("LSM_FRONTEND_SPLIT") != "1")
+
     def _audio(self, audio) -> torch.Tensor:
         if isinstance(audio, np.ndarray):
             audio = torch.from_numpy(np.ascontiguousarray(audio, dtype=np.float32))
@@ -226,10 +233,13 @@ class SpikeFrontEnd:
         (fused launch only): caller-owned uint8 (B, C, n_steps) output and float64 scratch of at least
         `workspace_elems(B)` elements, so that a steady stream of batches makes no allocator call at all."""
         if fused is None:
-            # LSM_FRONTEND_SPLIT=1: diagnostic switch for same-box A/B runs of the two routes (exp/r03_fused_sweep.sh)
-            fused = (self.filterbank == "gammatone" and self.n_filters <= 1024
-                     and os.environ.get("LSM_FRONTEND_SPLIT") != "1")
+            fused = self.will_fuse()
         if not fused:
+            if raster_out is not None or workspace is not None:
+                # the split route allocates its own outputs on the current stream: a caller that owns the raster
+                # buffer (pipeline.HotPath's rings) must not be handed another tensor silently (ADVICE r3)
+                raise ValueError("raster_out / workspace belong to the fused launch; this front end takes the split "
+                                 "route (mel branch, > 1024 filters or LSM_FRONTEND_SPLIT=1)")
             db, _ = self.spectrogram_db(audio)
             raster, _ = self.spikes_from_db(db)
             return raster

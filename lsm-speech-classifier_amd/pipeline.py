@@ -167,10 +167,13 @@ class HotPath:
                     elif on_device:
                         fst.wait_stream(cur)
                     self._fe_done = [ev for ev in self._fe_done[-8:] if not ev.query()]
-                    idle = (self.wide_when_idle and len(self._fe_done) < self._wide_below
-                            and getattr(self.fe, "filterbank", "") == "gammatone")
+                    # the front end's own decision (mel branch, > 1024 filters and LSM_FRONTEND_SPLIT=1 take the split
+                    # route, which allocates its raster on the front-end stream): only the fused launch writes
+                    # into the pipeline's rings, everything else goes through record_stream below
+                    fuses = bool(getattr(self.fe, "will_fuse", lambda: False)())
+                    idle = self.wide_when_idle and len(self._fe_done) < self._wide_below and fuses
                     x = self._to_device(audio, ("fe", fslot))
-                    pooled = self.pool and stage == "full" and getattr(self.fe, "filterbank", "") == "gammatone"
+                    pooled = self.pool and stage == "full" and fuses
                     if pooled:
                         key = (fslot, int(x.shape[0]))
                         ring = self._rasters.get(key)
@@ -188,6 +191,7 @@ class HotPath:
                         rasters = self.fe.encode(x, low_latency=idle, raster_out=ring[0][bi], workspace=self._ws[key])
                     else:
                         rasters = self.fe.encode(x, low_latency=True) if idle else self.fe.encode(x)
+                        pooled = False
                     done = torch.cuda.Event()
                     done.record(fst)
                     self._fe_done.append(done)

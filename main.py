@@ -59,7 +59,8 @@ audio, labels = cd.collect_audio(commands=cd.commands_from_args(a), dataset_root
                                  synthetic_per_class=a.synthetic_per_class)
 ex.main_from_audio(audio, labels, a.n_filters, a.filterbank, a.feature_set, a.multiplier,
                    num_neurons=a.num_neurons, num_output_neurons=a.num_output_neurons,
-                   small_world_k=a.small_world_k, seed=a.seed)
+                   small_world_k=a.small_world_k, seed=a.seed, readout=a.device_readout,
+                   class_names=cd.commands_from_args(a))
 """
 
 
@@ -76,7 +77,9 @@ def run_pipeline(n_filters: int, filterbank: str, feature_set: str, multiplier: 
     """1. spike-train dataset, 2. LSM features, 3. readout.  A failing stage does not stop the
     next one (the reference discards exit codes too); it shows up as that stage's own message.
     `in_memory` (not in the reference): stages 1 and 2 run as ONE process (or one per GPU) that keeps audio,
-    rasters and features on the GPU (extract_lsm_features.main_from_audio; no File 1), then the readout as usual.
+    rasters and features on the GPU (extract_lsm_features.main_from_audio; no File 1), then the readout as usual --
+    except that a PyTorch readout (`readout="torch-ridge"` / `"torch-logistic"`) runs inside that process on the
+    feature rows still on the GPU and prints the final report itself (no stage 3 process, no File 2 reload).
     `extra`: the forwarded constants (commands, commands_file, dataset_root, max_per_class, synthetic_per_class,
     packed, num_neurons, num_output_neurons, small_world_k, seed, readout, nproc)."""
     args = argparse.Namespace(n_filters=n_filters, filterbank=filterbank, feature_set=feature_set,
@@ -92,6 +95,10 @@ def run_pipeline(n_filters: int, filterbank: str, feature_set: str, multiplier: 
     if in_memory:
         print("\n--- Steps 1+2: audio -> LSM features on the GPU (no dataset file) ---", flush=True)
         ns = {k: v for k, v in vars(args).items() if k not in ("readout", "nproc", "packed")}
+        # a PyTorch readout on the in-memory route runs where the features already are: scaler, readout and
+        # predictions on the GPU, no File 2 reload; File 2 is still written
+        device_readout = args.readout if args.readout in ("torch-ridge", "torch-logistic") else None
+        ns["device_readout"] = device_readout
         code = f"import sys; sys.path.insert(0, {HERE!r})\n" + IN_MEMORY.format(ns=ns)
         if args.nproc > 1:            # torch.distributed.run needs a file to start
             import tempfile
@@ -103,7 +110,7 @@ def run_pipeline(n_filters: int, filterbank: str, feature_set: str, multiplier: 
                 os.unlink(fh.name)
         else:
             subprocess.call([sys.executable, "-c", code])
-        stages = STAGES[2:]
+        stages = () if device_readout else STAGES[2:]
     else:
         stages = STAGES
     for i, (title, command) in enumerate(stages):

@@ -141,3 +141,74 @@ def test_fused_argument_errors(torch_cuda):
     assert call(red=0) == -1
     assert call(raster=None) == -1
     torch_cuda.cuda.synchronize()
+
+
+@pytest.mark.parametrize("n_filters", [640, 1024])
+def test_low_latency_flag_is_only_a_hint_above_512_filters(torch_cuda, oracle_c, n_filters):
+    """513..1024 filters need more than 8 one-chain waves per clip; the low-latency flag then keeps the
+    two-chain layout instead of failing, directly and as HotPath's first step after a synchronisation."""
+    from lsm_speech_classifier_amd import frontend, reservoir, snn, synth
+    from lsm_speech_classifier_amd.pipeline import HotPath
+    audio = synth.class_chirps([0, 5], seed=13)
+    fe = frontend.SpikeFrontEnd(n_filters, "gammatone")
+    plain = fe.encode(audio, fused=True)
+    assert torch_cuda.equal(plain, fe.encode(audio, fused=True, low_latency=True))
+    np.testing.assert_array_equal(plain[:1].cpu().numpy(), _oracle_raster(oracle_c, audio[:1], n_filters))
+    params = reservoir.SimulationParams(num_neurons=256, num_output_neurons=32, small_world_graph_k=16,
+                                        mean_weight=0.02)
+    net = snn.SNN(params, n_channels=n_filters)
+    hp = HotPath(fe, net, None)                      # default topology: its first front end meets an idle GPU
+    dev_audio = torch_cuda.from_numpy(audio).cuda()
+    feats, st = hp.submit(dev_audio)
+    hp.synchronize()
+    ref, _, _ = net.run_batch(plain)
+    torch_cuda.cuda.synchronize()
+    assert torch_cuda.equal(feats, ref)
+
+
+def test_negative_hysteresis_gap_clears_an_active_latch_like_the_reference(torch_cuda, oracle_c):
+    """with off > on (a negative gap) an active latch can see S and R together; the reference takes
+    rising and falling from the latch before the update (create_dataset.py:90-95), so the latch is cleared."""
+    from lsm_speech_classifier_amd import frontend, synth
+    from oracle import ref_numpy as O
+    rng = np.random.RandomState(4)
+    audio = np.concatenate([synth.class_chirps([1, 8, 10], seed=2), synth.white_noise(2, seed=9)])
+    for gap in (-0.05, -0.2):
+        thr = sorted(rng.uniform(0.3, 0.95, size=4).tolist())
+        fe = frontend.SpikeFrontEnd(96, "gammatone", thresholds=thr, gap=gap)
+        got = fe.encode(audio, fused=True)
+        assert torch_cuda.equal(got, fe.encode(audio, fused=False))
+        assert torch_cuda.equal(got, fe.encode(audio, fused=True, low_latency=True))
+        ref = _oracle_raster(oracle_c, audio, 96, thr=thr, gap=gap)
+        np.testing.assert_array_equal(got.cpu().numpy(), ref)
+        # and the literal NumPy restatement of the reference's loop agrees with the C port on this case
+        coefs = O.gammatone_coefs(16000, 96, 50)
+        norm = oracle_c.normalise_resize(oracle_c.gammatone_db(oracle_c.gammatone_spec(audio[0], coefs, 400, 160, 98)), 100)
+        np.testing.assert_array_equal(O.encode_hysteresis(norm, thr, gap), ref[0])
+
+
+def test_split_route_refuses_caller_owned_buffers(torch_cuda, monkeypatch):
+    """raster_out / workspace belong to the fused launch; the split route (here forced) must not drop them
+    silently -- pipeline.HotPath relies on `will_fuse()` to decide who owns the raster buffer."""
+    from lsm_speech_classifier_amd import frontend, reservoir, snn, synth
+    from lsm_speech_classifier_amd.pipeline import HotPath
+    audio = torch_cuda.from_numpy(synth.class_chirps([0, 5, 7], seed=1)).cuda()
+    fe = frontend.SpikeFrontEnd(64, "gammatone")
+    want = fe.encode(audio)
+    buf = torch_cuda.empty((3, 64, 400), dtype=torch_cuda.uint8, device="cuda")
+    monkeypatch.setenv("LSM_FRONTEND_SPLIT", "1")
+    assert not fe.will_fuse()
+    with pytest.raises(ValueError):
+        fe.encode(audio, raster_out=buf)
+    # the pipeline on the split route: rasters come from the allocator and are handed over with record_stream
+    params = reservoir.SimulationParams(num_neurons=256, num_output_neurons=32, small_world_graph_k=16,
+                                        mean_weight=0.02)
+    net = snn.SNN(params, n_channels=64)
+    hp = HotPath(fe, net, None)
+    rows = [hp.submit(audio)[0] for _ in range(8)]
+    hp.synchronize()
+    assert not hp._rasters                              # no pipeline-owned raster ring was touched
+    ref, _, _ = net.run_batch(want)
+    torch_cuda.cuda.synchronize()
+    for r in rows:
+        assert torch_cuda.equal(r, ref)

@@ -64,6 +64,60 @@ def test_in_memory_route_writes_the_same_file_2(tmp_path, monkeypatch):
         assert str(d["feature_set"]) == "original"
 
 
+def test_in_memory_route_keeps_the_features_on_the_device_for_a_torch_readout(tmp_path, monkeypatch, capsys):
+    """SURVEY.md 8f-2 / VERDICT r3 #6: with a PyTorch readout the gathered rows go device -> readout.StandardScaler ->
+    ridge -> predictions without a host copy (the reference's round trip: extract_lsm_features.py:199-212 ->
+    train_classifier.py:27-45); File 2 is still written.  cfg4-shaped corpus (35 classes, N = 4000, ring-row kernel):
+    the predictions equal scikit-learn's RidgeClassifier on the host route's File 2."""
+    import torch
+    import create_dataset as cd
+    import extract_lsm_features as ex
+    import train_classifier as tc
+    from sklearn.linear_model import RidgeClassifier
+    from lsm_speech_classifier_amd import readout as ro
+    monkeypatch.chdir(tmp_path)
+    words = [f"word{i:02d}" for i in range(35)]
+    audio, labels = cd.collect_audio(commands=words, synthetic_per_class=5)
+
+    seen = {}
+    real_fit, real_report = ro.StandardScaler.fit, tc.report_results
+
+    def spy_fit(self, X):
+        assert torch.is_tensor(X) and X.is_cuda and X.dtype == torch.float32     # no .cpu() before the scaler
+        seen["scaler_rows"] = tuple(X.shape)
+        return real_fit(self, X)
+
+    def spy_report(y_train, y_test, y_pred, class_names=None):
+        seen["y_pred"], seen["y_test"] = np.asarray(y_pred), np.asarray(y_test)
+        return real_report(y_train, y_test, y_pred, class_names)
+
+    monkeypatch.setattr(ro.StandardScaler, "fit", spy_fit)
+    monkeypatch.setattr(tc, "report_results", spy_report)
+    acc = ex.main_from_audio(audio, labels, 128, "gammatone", "original", 0.6, num_neurons=4000,
+                             readout="torch-ridge", class_names=words)
+    out = capsys.readouterr().out
+    assert "Test Accuracy" in out and "word34" in out and "ridge classifier on the device" in out
+    assert seen["scaler_rows"] == (140, 5 * 1600) and 0.0 <= acc <= 1.0
+    with np.load(ex.FEATURE_FILE, allow_pickle=True) as d:
+        dev_file = {k: d[k] for k in d.files}
+    os.remove(ex.FEATURE_FILE)
+
+    # the host route on the same clips: sklearn's scaler (the reference's), sklearn's ridge
+    monkeypatch.setattr(ro.StandardScaler, "fit", real_fit)
+    assert ex.main_from_audio(audio, labels, 128, "gammatone", "original", 0.6, num_neurons=4000) is None
+    with np.load(ex.FEATURE_FILE, allow_pickle=True) as d:
+        host_file = {k: d[k] for k in d.files}
+    assert sorted(dev_file) == sorted(host_file)
+    for k in ("y_train", "y_test"):
+        np.testing.assert_array_equal(dev_file[k], host_file[k])
+    for k in ("X_train_features", "X_test_features"):
+        assert dev_file[k].dtype == host_file[k].dtype == np.float32
+        np.testing.assert_allclose(dev_file[k], host_file[k], rtol=2e-5, atol=2e-6)
+    clf = RidgeClassifier(alpha=1.0).fit(host_file["X_train_features"], host_file["y_train"])
+    np.testing.assert_array_equal(seen["y_test"], host_file["y_test"])
+    np.testing.assert_array_equal(seen["y_pred"], clf.predict(host_file["X_test_features"]))
+
+
 @pytest.mark.parametrize("exchange", ["once", "per-step"])
 def test_bench_spawns_two_ranks_on_a_shared_gpu(exchange):
     """`bench.py --gpus 2` starts its own ranks; both exchange modes: ONE all-gather of every step's rows after the

@@ -50,15 +50,29 @@ class _TorchReadout:
 READOUTS = ("sklearn", "torch-ridge", "torch-logistic")
 
 
+def report_results(y_train, y_test, y_pred, class_names=None):
+    """The reference's final report (train_classifier.py:47-52): accuracy + per-class table.  Shared by the file
+    route below and by extract_lsm_features.main_from_audio(readout=...), whose readout ran on the device."""
+    from sklearn.metrics import accuracy_score, classification_report
+    class_names = list(CLASS_NAMES if class_names is None else class_names)
+    accuracy = accuracy_score(y_test, y_pred)
+    present = sorted(set(np.unique(y_train)) | set(np.unique(y_test)))
+    names = [class_names[i] if i < len(class_names) else f"class_{i}" for i in present]
+    report = classification_report(y_test, y_pred, labels=present, target_names=names, zero_division=0)
+    print("\n--- Final Results ---")
+    print(f"Test Accuracy: {accuracy * 100:.2f}%\n")
+    print("Classification Report:")
+    print(report)
+    return accuracy
+
+
 def train_and_evaluate_classifier(readout=None, class_names=None):
     """The reference's function (no arguments there).  `readout`: one of READOUTS (default: LSM_READOUT, else the
     reference's scikit-learn logistic regression); `class_names`: report names when the dataset was built with
     another class list than the reference's 12 words (train_classifier.py:8-20 hard-codes them)."""
-    from sklearn.metrics import accuracy_score, classification_report
     readout = readout or os.environ.get("LSM_READOUT", "sklearn")
     if readout not in READOUTS:
         raise ValueError(f"readout must be one of {READOUTS}, got {readout!r}")
-    class_names = list(CLASS_NAMES if class_names is None else class_names)
     if not Path(FEATURE_FILE).exists():
         print("Error: Dataset file not found. Please run 'extract_lsm_features.py' first.")
         return
@@ -75,15 +89,7 @@ def train_and_evaluate_classifier(readout=None, class_names=None):
 
     print("Evaluating performance on the test set...")
     y_pred = clf.predict(X_test)
-    accuracy = accuracy_score(y_test, y_pred)
-    present = sorted(set(np.unique(y_train)) | set(np.unique(y_test)))
-    names = [class_names[i] if i < len(class_names) else f"class_{i}" for i in present]
-    report = classification_report(y_test, y_pred, labels=present, target_names=names, zero_division=0)
-    print("\n--- Final Results ---")
-    print(f"Test Accuracy: {accuracy * 100:.2f}%\n")
-    print("Classification Report:")
-    print(report)
-    return accuracy
+    return report_results(y_train, y_test, y_pred, class_names)
 
 
 if __name__ == "__main__":
