@@ -87,10 +87,16 @@ def parse_args(argv=None):
                     help="set-up, before the W warm-up steps: HotPath.prime() keeps the pipeline running untimed for this "
                          "long so that the timed steps see the clock a running pipeline holds, not the ramp after an idle "
                          "set-up phase (0 = one step per stream only)")
-    ap.add_argument("--exchange", default="once", choices=["once", "per-step"],
-                    help="N > 1: 'once' = every rank keeps its steps' feature rows and ONE all-gather follows the "
-                         "last step, inside the timed region (what the product does: one gather per split, "
-                         "extract_lsm_features.py); 'per-step' = an all-gather behind every step's reservoir kernel")
+    ap.add_argument("--exchange", default="chunked", choices=["chunked", "once", "per-step"],
+                    help="N > 1: 'chunked' = the rows of every --exchange-chunk steps travel in one all-gather on a stream "
+                         "of its own as soon as those steps have finished, so only the last chunk's gather is exposed "
+                         "behind the last step; 'once' = ONE all-gather after the last step, inside the timed region "
+                         "(what the product does per split, extract_lsm_features.py, where it is negligible); "
+                         "'per-step' = an all-gather behind every step's reservoir kernel")
+    ap.add_argument("--exchange-chunk", type=int, default=5, help="steps per all-gather of the chunked exchange")
+    ap.add_argument("--no-unprimed", action="store_true",
+                    help="skip the first, unprimed pass (one step per stream, W warm-up steps, K timed steps: the "
+                         "round-2 protocol) whose figure the line reports as `unprimed` beside the headline")
     return ap.parse_args(argv)
 
 
@@ -231,6 +237,12 @@ def cpu_baseline(cfg, audio, res, seconds_budget=24.0):
 
 
 def run_rank(args):
+    if int(os.environ.get("WORLD_SIZE", "1")) > 1 or os.environ.get("LSM_BENCH_FORCE_DIST") == "1":
+        # 5 front-end + 6 reservoir streams + the default stream fill the package's 12 hardware queues; the exchange
+        # stream and RCCL's own stream must not share a queue with a pipeline stream (kernels of streams on one queue
+        # serialise: profiles/r03_burst_decomposition.txt, 6 + 6 streams on 12 queues).  16 queues run the pipeline
+        # as fast as 12 (same file).  Read once, when HIP initialises: set before the package is imported.
+        os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
     import lsm_speech_classifier_amd                # noqa: F401  (sets GPU_MAX_HW_QUEUES before HIP initialises)
     from lsm_speech_classifier_amd import pipeline  # noqa: F401
     import numpy as np
@@ -292,15 +304,17 @@ def run_rank(args):
     lay = net.layout(B, fe.n_steps, hp.waves_per_clip)
     audio_pinned = torch.from_numpy(audio_np).pin_memory() if args.from_host else None
     per_step = use_dist and args.exchange == "per-step"
-    # one exchange keeps every step's rows of every rank in one block: fall back to the per-step gather when that block
-    # would not be small next to the HBM (cfg5 over hundreds of steps), and say so in config.sharding
+    # 'once' / 'chunked' keep every step's rows of every rank in one block: fall back to the per-step gather when that
+    # block would not be small next to the HBM (cfg5 over hundreds of steps), and say so in config.sharding
     gather_block_bytes = world * max(args.steps, 1) * B * n_feat * 4
     if use_dist and not per_step and gather_block_bytes > (16 << 30):
         per_step = True
         if rank == 0:
             print(f"bench.py: one exchange would need a {gather_block_bytes / 2**30:.1f} GiB gather block; "
                   f"gathering behind every step instead", file=sys.stderr)
-    once = use_dist and not per_step
+    once = use_dist and not per_step                 # rows kept per rank, gathered in one or several pieces
+    chunk = max(1, min(args.exchange_chunk, max(args.steps, 1))) if args.exchange == "chunked" else max(args.steps, 1)
+    xs = torch.cuda.Stream(device=dev) if once and args.exchange == "chunked" else None     # the exchange's own stream
     stage_in = rasters0 if args.stage == "reservoir" else (audio_pinned if args.from_host else audio)
     # per-step exchange: one gather buffer per stream of the rotation (overlapping steps never share an output);
     # one exchange: every step writes its rows into its own slice of a per-rank block, gathered once at the end
@@ -312,9 +326,25 @@ def run_rank(args):
     gathered = (torch.empty((world * args.steps * B, n_feat), dtype=torch.float32, device=dev)
                 if local_rows is not None else None)
 
-    def step(i):
+    done_events = []                    # one event per step of the current phase (warm-up or timed), behind its last launch
+
+    def gather_chunk(c0, c1):
+        """All-gather the rows of steps [c0, c1) of every rank.  `gathered` is laid out chunk by chunk, each chunk rank
+        by rank: chunk [c0, c1) occupies rows [world*c0*B, world*c1*B), rank r's steps inside it follow one another."""
+        dst = gathered[world * c0 * B: world * c1 * B]
+        dist.all_gather_into_tensor(dst, local_rows[c0:c1].reshape((c1 - c0) * B, n_feat))
+
+    def gather_behind(c0, c1):
+        """The chunk's all-gather on the exchange stream, ordered behind the chunk's steps (GPU-side waits only).
+        RCCL orders its own stream behind `xs`; no pipeline stream ever waits for a gather."""
+        with torch.cuda.stream(xs):
+            for ev in done_events[c0:c1]:
+                xs.wait_event(ev)
+            gather_chunk(c0, c1)
+
+    def step(i, n_exchanged=0):
         """One pass of the hot path over the batch on the next stream of the rotation (HotPath.submit, also for
-        the --stage variants)."""
+        the --stage variants).  `n_exchanged`: steps of this phase whose rows take part in the exchange."""
         slot = hp._step % hp.n_streams
         out_rows = local_rows[i] if local_rows is not None else None
         feats, st = hp.submit(stage_in, out=out_rows, stage=args.stage)
@@ -323,17 +353,34 @@ def run_rank(args):
             # gather; with >= 12 hardware queues the exchange does not disturb the other steps in flight
             with torch.cuda.stream(st):
                 dist.all_gather_into_tensor(gather_bufs[slot], feats)
-            return gather_bufs[slot]
+            feats = gather_bufs[slot]
+        if gathered is not None:
+            ev = torch.cuda.Event(enable_timing=True)
+            ev.record(st if st is not None else torch.cuda.current_stream(dev))
+            done_events.append(ev)
+            if xs is not None and (i + 1) % chunk == 0 and i + 1 <= n_exchanged:
+                gather_behind(i + 1 - chunk, i + 1)      # this chunk's rows travel while the next steps run
         return feats
 
-    def exchange_once(n_steps):
-        """What the product does (extract_lsm_features.py: one gather per split): the rows of all `n_steps` steps
-        of this rank travel in ONE all-gather, ordered behind every stream of the rotation without a host wait."""
-        if gathered is None:
+    def finish_exchange(n_steps):
+        """What is still due of the exchange after the last step, inside the timed region: 'once' = the one all-gather
+        behind every stream of the pipeline (no host wait); 'chunked' = the tail chunk (when the chunk size does not
+        divide the steps) and the edge that makes the current stream wait for the exchange stream.  Returns an
+        event behind the whole exchange."""
+        if gathered is None or n_steps <= 0:
             return None
-        hp.join_to_current()
-        dist.all_gather_into_tensor(gathered[: world * n_steps * B], local_rows[:n_steps].reshape(n_steps * B, n_feat))
-        return gathered
+        cur = torch.cuda.current_stream(dev)
+        if xs is None:
+            hp.join_to_current()
+            gather_chunk(0, n_steps)
+        else:
+            sent = (n_steps // chunk) * chunk
+            if sent < n_steps:
+                gather_behind(sent, n_steps)
+            cur.wait_stream(xs)
+        end = torch.cuda.Event(enable_timing=True)
+        end.record(cur)
+        return end
 
     def fence():
         torch.cuda.synchronize()
@@ -341,27 +388,56 @@ def run_rank(args):
             dist.barrier()
             torch.cuda.synchronize()
 
-    # set-up: every stream's allocator pool and first launch, and the GPU's clock at its working point
-    primed_steps = hp.prime(stage_in, stage=args.stage, min_ms=args.prime_ms)
-    hp.fork_from_current()             # inputs were produced on the default stream
-    for i in range(args.warmup):
-        out = step(i)
-    if args.warmup and gathered is not None:
-        exchange_once(min(args.warmup, args.steps))   # RCCL's own one-off set-up belongs to the warm-up too
-    fence()
-    hp.reservoir_events.clear()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        out = step(i)
-    host_enqueue_ms = (time.perf_counter() - t0) / args.steps * 1e3      # host side of a step (asynchronous)
-    if gathered is not None:
-        out = exchange_once(args.steps)                                  # inside the timed region, before the fence
-    fence()
-    elapsed = time.perf_counter() - t0
-    if use_dist:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    def timed_pass(prime_ms):
+        """Set-up (prime), W untimed warm-up steps, then EXACTLY K timed steps between two fences."""
+        primed = hp.prime(stage_in, stage=args.stage, min_ms=prime_ms)
+        hp.fork_from_current()             # inputs were produced on the default stream
+        n_w = min(args.warmup, args.steps)
+        done_events.clear()
+        for i in range(args.warmup):
+            step(i, n_w)
+        finish_exchange(n_w)               # RCCL's own one-off set-up belongs to the warm-up too
+        fence()
+        hp.reservoir_events.clear()
+        done_events.clear()
+        t0 = time.perf_counter()
+        out = None
+        for i in range(args.steps):
+            out = step(i, args.steps)
+        enqueue_ms = (time.perf_counter() - t0) / args.steps * 1e3      # host side of a step (asynchronous)
+        x_end = finish_exchange(args.steps)                              # inside the timed region, before the fence
+        fence()
+        elapsed = time.perf_counter() - t0
+        if use_dist:
+            t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            elapsed = float(t.item())
+        # exposed tail of the exchange: from the moment the LAST step finished (whichever stream it ran on) to the end
+        # of the exchange -- what the collective adds to the timed region
+        exposed = None
+        if x_end is not None and done_events:
+            exposed = max(0.0, min(ev.elapsed_time(x_end) for ev in done_events))
+        return {"elapsed": elapsed, "enqueue_ms": enqueue_ms, "primed": primed, "out": out, "exchange_ms": exposed,
+                "ev_pairs": list(hp.reservoir_events)}
+
+    # ADVICE r3: the 40 ms of HotPath.prime() are a measurement-protocol choice (the clock governor at its working
+    # point, profiles/r03_clock_ramp.txt).  The first pass keeps round 2's protocol -- one step per stream, W warm-up
+    # steps, K timed steps -- and its figure is reported as `unprimed`; the second pass is the headline.
+    unprimed = None
+    if world == 1 and not use_dist and not args.no_unprimed and args.prime_ms > 0:
+        u = timed_pass(0.0)
+        unprimed = {"value": round(B * args.steps / u["elapsed"], 2), "ms_per_step": round(u["elapsed"] / args.steps * 1e3, 4),
+                    "protocol": f"first pass of this run: {u['primed']} untimed steps (one per stream) + {args.warmup} "
+                                f"warm-up steps, then {args.steps} timed steps (the round-2 protocol)"}
+    res_pass = timed_pass(args.prime_ms)
+    elapsed, host_enqueue_ms, primed_steps, out = (res_pass["elapsed"], res_pass["enqueue_ms"], res_pass["primed"],
+                                                   res_pass["out"])
+    exchange_ms = res_pass["exchange_ms"]
+    if use_dist and exchange_ms is not None:             # the slowest rank's tail
+        t = torch.tensor([exchange_ms], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        exchange_ms = float(t.item())
+    hp.reservoir_events[:] = res_pass["ev_pairs"]
     ev_pairs = list(hp.reservoir_events)
 
     def median_ms(fn, reps=5):
@@ -395,9 +471,19 @@ def run_rank(args):
     if args.stage != "frontend":
         rows = local_rows[args.steps - 1] if local_rows is not None else out[:B]
         spikes_per_clip = float(rows.float()[:, :cfg["n_out"]].sum(dim=1).mean())
-        if gathered is not None:       # the gathered block holds every rank's rows: this rank's come back unchanged
-            mine = gathered[rank * args.steps * B: (rank + 1) * args.steps * B]
-            assert torch.equal(mine, local_rows[:args.steps].reshape(-1, n_feat)), "all-gather returned other rows"
+    exchange_digest = None
+    if gathered is not None and args.stage != "frontend":
+        # the gathered block holds every rank's rows, chunk by chunk: put them back into (rank, step, clip) order --
+        # this rank's rows must come back unchanged, and the digest of the whole block is the same number whatever the
+        # exchange mode (tests/test_gpu_hotpath.py compares 'once' and 'chunked')
+        bounds = [(c0, min(c0 + chunk, args.steps)) for c0 in range(0, args.steps, chunk)]
+        by_rank = [torch.cat([gathered[world * c0 * B + r * (c1 - c0) * B: world * c0 * B + (r + 1) * (c1 - c0) * B]
+                              for c0, c1 in bounds]) for r in range(world)]
+        assert torch.equal(by_rank[rank], local_rows[:args.steps].reshape(-1, n_feat)), "all-gather returned other rows"
+        canon = torch.cat(by_rank).view(torch.int32).to(torch.int64).reshape(-1)
+        weights = torch.arange(canon.numel(), device=dev, dtype=torch.int64) % 65521 + 1
+        exchange_digest = int((canon * weights).sum().item())            # wraps in int64: deterministic
+        del by_rank, canon, weights
 
     if rank == 0:
         ms_step = elapsed / args.steps * 1e3
@@ -428,17 +514,30 @@ def run_rank(args):
                                     "pipeline.HotPath: steps rotate over the streams" if not hp.n_fe_streams else
                                     "pipeline.HotPath: front ends on their own streams, reservoir launches behind events"),
                        "mean_output_spikes_per_clip": spikes_per_clip,
-                       "sharding": (f"clips x{world}, one feature all-gather after the last step (as the product: one "
-                                    f"gather per split)" if once else
+                       "sharding": ((f"clips x{world}, feature rows all-gathered every {chunk} steps on a stream of their "
+                                     f"own while the next steps run; only the last chunk's gather is exposed"
+                                     if xs is not None else
+                                     f"clips x{world}, one feature all-gather after the last step (as the product: one "
+                                     f"gather per split)") if once else
                                     f"clips x{world}, feature all-gather behind every step") if use_dist and world > 1
                                    else ("single GPU" if not use_dist else f"1 rank, distributed code path ({args.exchange})")},
         }
+        if unprimed is not None:
+            line["unprimed"] = unprimed
+        if use_dist and once and args.stage != "frontend":
+            line["exchange"] = {
+                "mode": args.exchange, "chunk_steps": chunk if xs is not None else args.steps,
+                "exchange_ms": None if exchange_ms is None else round(exchange_ms, 4),
+                "exchange_bytes": world * args.steps * B * n_feat * 4,
+                "bytes_sent_per_rank": args.steps * B * n_feat * 4, "digest": exchange_digest,
+                "note": "exchange_ms = exposed tail: from the moment the last step's kernels finished to the end of the "
+                        "exchange (HIP events, max over ranks), inside the timed region; exchange_bytes = what every "
+                        "rank holds afterwards"}
         if ev_pairs:
             lif_ms = sum(a.elapsed_time(b) for a, b in ev_pairs) / len(ev_pairs)
             w_bytes = res.csr_bytes()
             per_clip = fe.n_channels * fe.n_steps + n_feat * 4 + fe.n_steps * w_bytes / B
             compulsory = fe.n_channels * fe.n_steps + n_feat * 4 + w_bytes / B
-            achieved = per_clip * B / (lif_ms * 1e-3) / 1e9
             kname = {"dense": "lif_dense_kernel", "ring": "lif_ring_kernel", "sparse": "lif_kernel"}[net.kernel_in_use()]
             traffic = None
             tfile = os.environ.get("LSM_TRAFFIC_FILE") or os.path.join(ROOT, "profiles", "lif_traffic.json")
@@ -447,46 +546,67 @@ def run_rank(args):
                 traffic = json.load(open(tfile)).get(tkey)
             # NOT measured in this run: the PMC passes are separate rocprofv3 runs whose per-launch result is committed
             traffic_source = (f"{os.path.relpath(tfile, ROOT)}[{tkey}]: rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE, separate "
-                              f"passes on lone launches, (2*FETCH + WRITE)*1024 per launch -- a committed constant, "
+                              f"passes on lone launches of the product's launch (clips started longest first where the "
+                              f"product does), (2*FETCH + WRITE)*1024 per launch -- a committed constant, "
                               f"not measured in this run" if traffic is not None else
                               f"none: {os.path.relpath(tfile, ROOT)} has no entry '{tkey}' (no --pmc passes were "
                               f"collected for this shape)")
-            plan = net.plan(B, fe.n_steps, hp.waves_per_clip)
+            # The layout of a LONE launch is what `kernel_ms` times, so its plan is what the gather figures describe
+            plan = net.plan(B, fe.n_steps, 0)
             ceiling, ceiling_note = gather_ceiling_gbs(plan["table_bytes"])
-            row_bytes = plan["table_bytes"] / cfg["N"]
+            row_bytes = plan["row_request_bytes"]
+            # `frac` is built on a duration that cannot exceed the step time and does not move with the
+            # number of launches the pipeline happens to overlap -- the lone launch, timed in this run with HIP events
+            # on the stream the kernel is launched on (median of 5).  The HIP-event average over the timed region
+            # (launches of consecutive steps overlapping each other and the front ends) is reported beside it as
+            # in_region_*: it grows when the pipeline overlaps MORE, i.e. when throughput rises.
+            k_ms = lone_ms if lone_ms is not None else lif_ms
+            achieved = per_clip * B / (k_ms * 1e-3) / 1e9
+            bound_by = {
+                "dense": "per-step issue/latency chain of one clip (weight table L2-resident, HBM idle): neither HBM nor "
+                         "the L2 gather rate is the limit",
+                "ring": ("gather rate of the Infinity Cache / fabric (table beyond the L2s, most of it re-read per clip)"
+                         if plan["table_bytes"] > 40e6 else
+                         "row-gather latency at the occupancy LDS and registers allow (table in the Infinity Cache, "
+                         "bandwidth far from saturated)"),
+                "sparse": "ordered LDS read-modify-write chain per step"}[net.kernel_in_use()]
             line["roofline"] = {
                 "bound": "hbm", "kernel": kname, "achieved": round(achieved, 2),
                 "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
-                "traffic": traffic, "traffic_source": traffic_source, "kernel_ms": round(lif_ms, 4),
+                "traffic": traffic, "traffic_source": traffic_source, "kernel_ms": round(k_ms, 4),
+                "kernel_ms_source": "lone launch of the batch in the library's own layout, HIP events on the launch "
+                                    "stream, median of 5, measured in this run after the timed region",
+                "bound_by": bound_by,
                 "bytes_per_clip": round(per_clip, 1),
                 "variant": "streamed (C*T + 4*F_feat + T*|W|/B, SURVEY.md 8d); |W| = 8 B x nnz",
                 "traffic_over_algorithmic": None if traffic is None else round(traffic / (per_clip * B), 3),
                 "compulsory_bytes_per_clip": round(compulsory, 1),
-                "compulsory_gbs": round(compulsory * B / (lif_ms * 1e-3) / 1e9, 3),
-                "kernel_clips_per_s": round(B / (lif_ms * 1e-3), 1),
-                # the same algorithmic bytes against the WALL CLOCK of the path: one launch's bytes are consumed per step,
-                # however many launches overlap (kernel_ms / ms_per_step of them are in flight on average)
-                "launches_in_flight": round(lif_ms / ms_step, 2),
+                "compulsory_gbs": round(compulsory * B / (k_ms * 1e-3) / 1e9, 3),
+                "kernel_clips_per_s": round(B / (k_ms * 1e-3), 1),
+                "lone_launch_waves_per_clip": plan["waves_per_clip"],
+                # the same algorithmic bytes against the WALL CLOCK of the path: one launch's bytes are consumed per step
                 "pipeline_gbs": round(per_clip * B / (ms_step * 1e-3) / 1e9, 2),
                 "pipeline_frac": round(per_clip * B / (ms_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
-                "note": "kernel_ms is the HIP-event average over the timed region, where launches of "
-                        "consecutive steps overlap on the GPU; idle_gpu_* is the same launch (same layout) alone; "
-                        "lone_launch_* is a lone launch in the layout the library picks for it",
-                "lone_launch_kernel_ms": None if lone_ms is None else round(lone_ms, 4),
-                "lone_launch_frac": None if lone_ms is None else
-                round(per_clip * B / (lone_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
-                "lone_launch_waves_per_clip": net.layout(B, fe.n_steps, 0)["waves_per_clip"],
+                # inside the timed region: duration of a launch while others overlap it, and how many do on average
+                "in_region_kernel_ms": round(lif_ms, 4),
+                "in_region_frac": round(per_clip * B / (lif_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
+                "launches_in_flight": round(lif_ms / ms_step, 2),
+                "in_region_waves_per_clip": lay["waves_per_clip"],
                 "idle_gpu_kernel_ms": None if serial_ms is None else round(serial_ms, 4),
                 "idle_gpu_frac": None if serial_ms is None else
                 round(per_clip * B / (serial_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
+                "note": "frac = achieved / peak with achieved = algorithmic bytes of one launch / kernel_ms (the lone "
+                        "launch); in_region_* = the HIP-event average over the timed region, where launches of consecutive "
+                        "steps overlap (not a throughput figure); idle_gpu_* = the pipeline's layout launched alone",
                 # what an event-driven kernel really asks of the memory system: one weight row per reservoir spike
                 "weight_table_bytes": plan["table_bytes"], "gather_ceiling": ceiling, "gather_ceiling_note": ceiling_note,
                 "row_gather": None if lone_ms is None or spikes_total is None else {
                     "rows_per_launch": spikes_total, "mean_row_bytes": round(row_bytes, 1),
                     "gbs_lone_launch": round(spikes_total * row_bytes / (lone_ms * 1e-3) / 1e9, 1),
                     "frac_of_gather_ceiling": round(spikes_total * row_bytes / (lone_ms * 1e-3) / 1e9 / ceiling, 4),
-                    "note": "reservoir spikes of the batch (stats_out of one untimed launch) x mean bytes of a weight "
-                            "row of the table in use / lone-launch time; served by L2 when the table fits it"},
+                    "note": "reservoir spikes of the batch (stats_out of one untimed launch) x the bytes ONE spike requests "
+                            "from the table in use (lsm_reservoir_row_request_bytes: the window's existing bytes + its list "
+                            "entries + row pointers, mean over rows; table padding is not charged) / lone-launch time"},
                 "memory_side_gbs_lone_launch": None if traffic is None or lone_ms is None else
                 round(traffic / (lone_ms * 1e-3) / 1e9, 1),
                 "memory_side_frac": None if traffic is None or lone_ms is None else

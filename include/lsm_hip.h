@@ -203,6 +203,13 @@ int lsm_reservoir_layout(const lsm_reservoir *h, int n_clips, int n_steps, int w
 int lsm_reservoir_plan(const lsm_reservoir *h, int n_clips, int n_steps, int waves_per_clip, int *kernel_out,
                        int *wpc_out, int *slots_out, int *lds_bytes_out, long *table_bytes_out);
 
+/* Bytes ONE reservoir spike makes the planned kernel request from its weight table, mean over the presynaptic
+ * neurons (what bench.py's `roofline.row_gather` charges per spike; padding of the table is not charged): dense rows
+ * ld x 4; ring rows the window's existing bytes (128-byte-aligned start .. window end, 16-byte granules) + 8 bytes per
+ * list entry + the (waves + 1) row pointers; sparse 8 bytes per synapse + the two row pointers. */
+int lsm_reservoir_row_request_bytes(const lsm_reservoir *h, int n_clips, int n_steps, int waves_per_clip,
+                                    double *mean_bytes_out);
+
 /* Diagnostic builds (-DLSM_STAMP=1) only: per-phase s_memtime sums of the reservoir kernel
  * (out8: 8 counters, HOST memory); all zeros in the shipped build. */
 int lsm_debug_lif_stamps(unsigned long long *out8, int reset);

@@ -48,6 +48,7 @@ _SIGS = {
                                      C.POINTER(c_int), C.POINTER(c_int)]),
     "lsm_reservoir_plan": (c_int, [c_void, c_int, c_int, c_int, C.POINTER(c_int), C.POINTER(c_int),
                                    C.POINTER(c_int), C.POINTER(c_int), C.POINTER(C.c_long)]),
+    "lsm_reservoir_row_request_bytes": (c_int, [c_void, c_int, c_int, c_int, C.POINTER(C.c_double)]),
     "lsm_debug_lif_stamps": (c_int, [c_void, c_int]),
 }
 

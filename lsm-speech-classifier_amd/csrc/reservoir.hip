@@ -87,6 +87,7 @@ struct lsm_reservoir {
     // j-H up to j+H, plus per-layout lists of the synapses outside it
     float *band = nullptr;
     uint32_t band_pitch = 0;
+    double band_bytes_sum = 0;       // sum over rows of the window bytes that exist (what a spike's window loads can touch)
     int band_h = 0, band_nq = 0, band_wsq = 0;
     int mode = 0;           // 0 auto, 1 sparse (CSC scatter through LDS), 2 dense rows, 3 ring rows,
                             // 4 ring rows with contiguous quad ownership only (tests)
@@ -348,6 +349,7 @@ int lsm_reservoir_create(lsm_reservoir **out, int num_neurons, int n_channels,
                     }
                 if ((rc = upload(&h->band, band))) { free_reservoir(h); return rc; }
                 h->band_pitch = pitch; h->band_h = H; h->band_nq = NQ; h->band_wsq = wsq;
+                for (int j = 0; j < N; ++j) h->band_bytes_sum += nbytes[j];
                 const int rwpcs[4] = {2, 4, 8, 16};
                 for (int vi = 0; vi < 8; ++vi) {
                     const int wpc = rwpcs[vi & 3];
@@ -830,6 +832,26 @@ int lsm_reservoir_plan(const lsm_reservoir *h, int n_clips, int n_steps, int wav
         *lds_bytes_out = (int)(p.kernel == 2 ? dense_lds_bytes(h, *p.v, n_steps) : lif_lds_bytes(h, *p.v, n_steps));
     if (table_bytes_out)
         *table_bytes_out = p.kernel == 2 ? (long)((size_t)h->N * h->ld * 4) : (long)(h->nnz * 8 + ((size_t)h->N + 1) * 4);
+    return LSM_OK;
+}
+
+extern "C" __attribute__((visibility("default")))
+int lsm_reservoir_row_request_bytes(const lsm_reservoir *h, int n_clips, int n_steps, int waves_per_clip,
+                                    double *mean_bytes_out)
+{
+    LSM_REQUIRE(h != nullptr && mean_bytes_out != nullptr, "lsm_reservoir_row_request_bytes: null argument");
+    LSM_REQUIRE(n_clips >= 0 && n_steps >= 1 && n_steps <= 65535, "bad n_clips/n_steps");
+    LSM_REQUIRE(waves_per_clip >= -1 && waves_per_clip <= 16, "waves_per_clip must be -1 (pipelined), 0 (choose) or 1..16");
+    RunPlan p;
+    const int rc = make_plan(h, n_clips, n_steps, waves_per_clip, &p);
+    if (rc) return rc;
+    const double n = (double)h->N;
+    if (p.kernel == 3)
+        *mean_bytes_out = (h->band_bytes_sum + (double)p.rv->n_rem * 8.0) / n + (p.rv->wpc + 1) * 4.0;
+    else if (p.kernel == 2)
+        *mean_bytes_out = (double)h->ld * 4.0;
+    else
+        *mean_bytes_out = (double)h->nnz * 8.0 / n + 8.0;
     return LSM_OK;
 }
 

@@ -183,13 +183,18 @@ class SNN:
 
     def plan(self, n_clips: int, n_steps: int, waves_per_clip: int = 0) -> dict:
         """What `run_batch` would launch for this batch: kernel, layout, LDS bytes per clip and the bytes of the
-        weight table that kernel gathers from (`lsm_reservoir_plan`)."""
+        weight table that kernel gathers from (`lsm_reservoir_plan`), plus the bytes one spike requests from it, mean
+        over the presynaptic neurons (`lsm_reservoir_row_request_bytes`)."""
         k, wpc, sl, lds, tab = C.c_int(), C.c_int(), C.c_int(), C.c_int(), C.c_long()
         _lib.check(self.lib.lsm_reservoir_plan(self._handle, n_clips, n_steps, waves_per_clip, C.byref(k),
                                                C.byref(wpc), C.byref(sl), C.byref(lds), C.byref(tab)),
                    "lsm_reservoir_plan")
+        rb = C.c_double()
+        _lib.check(self.lib.lsm_reservoir_row_request_bytes(self._handle, n_clips, n_steps, waves_per_clip,
+                                                            C.byref(rb)), "lsm_reservoir_row_request_bytes")
         return {"kernel": {1: "sparse", 2: "dense", 3: "ring"}[k.value], "waves_per_clip": wpc.value,
-                "slots_per_lane": sl.value, "lds_bytes": lds.value, "table_bytes": tab.value}
+                "slots_per_lane": sl.value, "lds_bytes": lds.value, "table_bytes": tab.value,
+                "row_request_bytes": rb.value}
 
     def layout(self, n_clips: int, n_steps: int, waves_per_clip: int = 0):
         wpc, sl, lds = C.c_int(), C.c_int(), C.c_int()

@@ -20,6 +20,34 @@ def _run(*extra):
     return json.loads(lines[0])
 
 
+def _fractions(obj, path=""):
+    """Every (path, value) in the line whose key says it is a fraction."""
+    if isinstance(obj, dict):
+        for k, v in obj.items():
+            if isinstance(v, (dict, list)):
+                yield from _fractions(v, f"{path}.{k}")
+            elif "frac" in k and v is not None:
+                yield f"{path}.{k}", v
+    elif isinstance(obj, list):
+        for i, v in enumerate(obj):
+            yield from _fractions(v, f"{path}[{i}]")
+
+
+def _check_fractions(d):
+    """a fraction above 1 is not evidence -- every `*frac*` of the line lies in [0, 1], and the duration
+    `roofline.frac` is built on cannot exceed what a launch takes inside the overlapped region."""
+    found = list(_fractions(d))
+    assert len(found) >= 4, found
+    for path, v in found:
+        assert 0.0 <= v <= 1.0, (path, v)
+    r = d["roofline"]
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-4
+    assert abs(r["achieved"] - r["bytes_per_clip"] * d["config"]["clips_per_gpu"] / (r["kernel_ms"] * 1e-3) / 1e9) \
+        < 1e-3 * r["achieved"] + 0.02
+    assert "lone launch" in r["kernel_ms_source"] and r["bound_by"]
+    assert abs(r["launches_in_flight"] - r["in_region_kernel_ms"] / d["ms_per_step"]) < 0.02
+
+
 def test_bench_line_contract():
     d = _run("--batch", "64")
     for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better",
@@ -34,6 +62,10 @@ def test_bench_line_contract():
         assert key in r, key
     assert r["bound"] == "hbm" and r["peak"] == 8000.0 and r["unit"] == "GB/s"
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-4 and r["kernel_ms"] > 0
+    _check_fractions(d)
+    # the figure of the round-2 protocol (no 40 ms of priming) travels beside the headline
+    u = d["unprimed"]
+    assert u["value"] > 0 and abs(u["value"] - 64 / (u["ms_per_step"] * 1e-3)) / u["value"] < 1e-3 and "round-2" in u["protocol"]
     # the line says where `traffic` comes from (never a silent null), and carries the gather ceiling
     assert r["traffic"] is None and r["traffic_source"].startswith("none:") and "cfg2_B64_dense" in r["traffic_source"]
     assert r["gather_ceiling"] == 16800.0 and 4e6 < r["weight_table_bytes"] < 4.5e6      # 1000 x 1024 x 4: L2 resident
@@ -51,15 +83,32 @@ def test_bench_line_names_the_committed_traffic_file_at_the_headline_shape():
     assert r["traffic"] > 0 and "profiles/lif_traffic.json[cfg2_B256_dense]" in r["traffic_source"]
     assert "not measured in this run" in r["traffic_source"]
     assert 0 < r["memory_side_frac"] < 1 and r["memory_side_gbs_lone_launch"] > 0
-    # the launch's algorithmic bytes against the wall clock of the path, beside the per-launch figure of the contract
-    assert abs(r["launches_in_flight"] - r["kernel_ms"] / d["ms_per_step"]) < 0.02 and r["launches_in_flight"] > 1
-    assert abs(r["pipeline_frac"] - r["frac"] * r["launches_in_flight"]) < 0.01 * r["pipeline_frac"] + 1e-4
+    _check_fractions(d)
+    # `frac` rests on the lone launch: not longer than a launch takes while others overlap it, nor than a step of the
+    # overlapped path times the launches in flight; the in-region figure and the wall-clock figure
+    # travel beside it
+    assert r["launches_in_flight"] > 1 and r["kernel_ms"] <= r["in_region_kernel_ms"] * 1.02
+    assert r["kernel_ms"] <= d["ms_per_step"] * r["launches_in_flight"] * 1.02
+    assert abs(r["pipeline_frac"] - r["in_region_frac"] * r["launches_in_flight"]) < 0.01 * r["pipeline_frac"] + 1e-4
+    assert r["frac"] >= r["in_region_frac"]
     assert d["config"]["reservoir_launch_order"] == "batch order"          # 256 clips: one per compute unit
     assert d["config"]["hw_queues"] == 12 and d["config"]["streams"] == 6 and d["config"]["fe_streams"] == 5
 
 
 def test_bench_stages_and_serial_mode():
     d = _run("--batch", "64", "--stage", "reservoir", "--no-cpu-baseline", "--streams", "1")
+    _check_fractions(d)
     assert "cpu_baseline" not in d and d["config"]["stage"] == "reservoir" and d["config"]["pipeline"] == "serial"
     d = _run("--batch", "64", "--stage", "frontend", "--no-cpu-baseline")
     assert "roofline" not in d and d["value"] > 0
+
+
+@pytest.mark.parametrize("config,batch", [("cfg4", "256"), ("cfg5", "64")])
+def test_fractions_of_the_large_configs_stay_within_one(config, batch):
+    """The ring-row kernel's gather figures charge a spike the bytes it requests, not the padded table: no fraction
+    of the cfg4 / cfg5 lines exceeds 1 (r03's cfg5 line read 1.22)."""
+    d = _run("--config", config, "--batch", batch, "--no-cpu-baseline", "--steps", "3", "--warmup", "1")
+    _check_fractions(d)
+    r = d["roofline"]
+    assert r["kernel"] == "lif_ring_kernel" and r["row_gather"]["mean_row_bytes"] * d["config"]["num_neurons"] \
+        <= r["weight_table_bytes"]

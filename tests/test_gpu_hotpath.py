@@ -118,22 +118,39 @@ def test_in_memory_route_keeps_the_features_on_the_device_for_a_torch_readout(tm
     np.testing.assert_array_equal(seen["y_pred"], clf.predict(host_file["X_test_features"]))
 
 
-@pytest.mark.parametrize("exchange", ["once", "per-step"])
-def test_bench_spawns_two_ranks_on_a_shared_gpu(exchange):
-    """`bench.py --gpus 2` starts its own ranks; both exchange modes: ONE all-gather of every step's rows after the
-    last step (the default: what the product does per split) and an all-gather behind every step."""
+def _bench_two_ranks(exchange, *extra):
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
     env.update(LSM_BENCH_SHARE_GPU="1", LSM_BENCH_BACKEND="gloo")
-    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "2",
-                        "--batch", "64", "--no-cpu-baseline", "--exchange", exchange], env=env, capture_output=True,
-                       text=True, timeout=600)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "6", "--warmup", "2",
+                        "--batch", "64", "--no-cpu-baseline", "--exchange", exchange, *extra], env=env,
+                       capture_output=True, text=True, timeout=600)
     assert p.returncode == 0, p.stderr[-3000:]
     lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["config"]["clips_per_gpu"] == 64 and "all-gather" in d["config"]["sharding"]
-    assert ("after the last step" in d["config"]["sharding"]) == (exchange == "once")
     assert abs(d["value"] - 2 * 64 / (d["ms_per_step"] * 1e-3)) / d["value"] < 1e-3
+    return d
+
+
+def test_bench_spawns_two_ranks_on_a_shared_gpu():
+    """`bench.py --gpus 2` starts its own ranks.  The exchange modes: rows gathered in chunks on a stream of their own
+    while the next steps run (the default; a chunk size that does not divide the steps leaves a tail chunk), ONE
+    all-gather after the last step (what the product does per split), an all-gather behind every step.  Chunked and
+    once deliver the SAME rows: the digest over the gathered block in (rank, step, clip) order is equal, and every
+    rank found its own rows back unchanged (asserted inside bench.py)."""
+    chunked = _bench_two_ranks("chunked", "--exchange-chunk", "4")          # chunks [0, 4) and the tail [4, 6)
+    once = _bench_two_ranks("once")
+    for d, mode, chunk in ((chunked, "chunked", 4), (once, "once", 6)):
+        x = d["exchange"]
+        assert x["mode"] == mode and x["chunk_steps"] == chunk
+        assert x["exchange_bytes"] == 2 * 6 * 64 * 2000 * 4 and x["bytes_sent_per_rank"] == 6 * 64 * 2000 * 4
+        assert x["exchange_ms"] is not None and 0.0 <= x["exchange_ms"] < d["ms_per_step"] * 6
+    assert chunked["exchange"]["digest"] == once["exchange"]["digest"] != 0
+    assert "every 4 steps" in chunked["config"]["sharding"] and "after the last step" in once["config"]["sharding"]
+    assert _bench_two_ranks("chunked", "--exchange-chunk", "3")["exchange"]["digest"] == once["exchange"]["digest"]
+    per_step = _bench_two_ranks("per-step")
+    assert "behind every step" in per_step["config"]["sharding"] and "exchange" not in per_step
 
 
 def test_bench_rccl_code_path_with_one_rank():
@@ -152,6 +169,9 @@ def test_bench_rccl_code_path_with_one_rank():
     assert p.returncode == 0, p.stderr[-3000:]
     d = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1])
     assert d["n_gpus"] == 1 and d["value"] > 1e4 and d["steps"] == 6
+    # the default exchange on RCCL: chunks of 5 steps on the exchange stream + the tail chunk, 16 hardware queues
+    assert d["exchange"]["mode"] == "chunked" and d["exchange"]["chunk_steps"] == 5 and d["config"]["hw_queues"] == 16
+    assert 0.0 <= d["exchange"]["exchange_ms"] < 5.0 and d["exchange"]["digest"] != 0
 
 
 @pytest.mark.parametrize("world,n", [(2, 9), (3, 2)])          # uneven shards; 3 ranks for 2 clips: an empty shard
