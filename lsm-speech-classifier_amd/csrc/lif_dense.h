@@ -79,7 +79,16 @@ struct DenseArgs {
 #else
 #define LSM_DENSE_VGPR_ATTR
 #endif
-template <int SL, int WPC, int INMODE>
+// REFM: the refractory countdown of the reference's period (REFRACTORY_PERIOD = 2, extract_lsm_features.py:13) lives in
+// SCALAR registers -- two 64-bit lane masks per slot, h2 = "fired at the last step" and h1 = "fired the step before" --
+// instead of one vector register per neuron.  The fire condition comes out of v_cmp as a lane mask, `held` = h1 | h2
+// and the countdown (h1 <- h2, h2 <- fire) are scalar mask moves, the potential's reset is ONE v_cndmask on the mask,
+// and the fire path takes the masks as execution masks: per neuron and step 2 vector instructions for threshold /
+// reset / refractory instead of ~9 (three compares, the boolean materialised and compared again for the ballot, two
+// selects, decrement, select).  The arithmetic on v is untouched.  Inside the pipeline the chip is bound by
+// vector-instruction issue, and scalar instructions issue beside it.  Other periods keep the vector
+// countdown (REFM = false).
+template <int SL, int WPC, int INMODE, bool REFM>
 __global__ __launch_bounds__(WPC * 64) LSM_DENSE_VGPR_ATTR void lif_dense_kernel(const DenseArgs a)
 {
     constexpr bool INREG = INMODE == 1;
@@ -141,15 +150,18 @@ __global__ __launch_bounds__(WPC * 64) LSM_DENSE_VGPR_ATTR void lif_dense_kernel
     }
 
     float v[SL], lam[SL];
-    int ref[SL], os[SL];
+    int ref[REFM ? 1 : SL], os[SL];
+    unsigned long long h1[REFM ? SL : 1], h2[REFM ? SL : 1];     // REFM: lanes whose countdown stands at 1 / at 2
 #pragma unroll
     for (int r = 0; r < SL; ++r) {
         const int i = (w * SL + r) * 64 + lane;
         v[r] = 0.0f;
-        ref[r] = 0;
+        if (REFM) { h1[r] = 0ull; h2[r] = 0ull; }
+        else ref[r] = 0;
         lam[r] = a.leak[i];
         os[r] = a.oslot[i];
     }
+
     uint32_t im[SL][4];                 // INMASK: channels 0..127 feeding my neuron r
     if (INMASK) {
 #pragma unroll
@@ -369,14 +381,24 @@ __global__ __launch_bounds__(WPC * 64) LSM_DENSE_VGPR_ATTR void lif_dense_kernel
                 icnt[i] = 0u;
             }
             cin[r] = cin[r] + w_in * (float)nin;         // SPEC.md §3: input term after the recurrent sum
-            const bool held = ref[r] > 0;
             const float m = lam[r] * v[r];
             const float d = v[r] - m;
             const float vn = d + cin[r];
-            const bool fire = !held && (vn >= theta);
-            v[r] = (held || fire) ? 0.0f : vn;
-            ref[r] = held ? ref[r] - 1 : (fire ? a.refractory : 0);
-            bal[r] = __ballot(fire);
+            if (REFM) {
+                const unsigned long long held = h1[r] | h2[r];
+                const unsigned long long ge = __builtin_amdgcn_fcmpf(vn, theta, 3 /* ordered >= */);
+                const unsigned long long fire = ge & ~held;
+                v[r] = __builtin_amdgcn_inverse_ballot_w64(ge | held) ? 0.0f : vn;
+                h1[r] = h2[r];                  // 2 -> 1 (and 1 -> 0: the old h1 is dropped)
+                h2[r] = fire;                   // a firing neuron (never a held one) starts at the period, 2
+                bal[r] = fire;
+            } else {
+                const bool held = ref[r] > 0;
+                const bool fire = !held && (vn >= theta);
+                v[r] = (held || fire) ? 0.0f : vn;
+                ref[r] = held ? ref[r] - 1 : (fire ? a.refractory : 0);
+                bal[r] = __ballot(fire);
+            }
             any_fire |= bal[r];
         }
         STAMP(3);
@@ -384,7 +406,8 @@ __global__ __launch_bounds__(WPC * 64) LSM_DENSE_VGPR_ATTR void lif_dense_kernel
         if (any_fire != 0ull) {                  // one branch per wave and step
 #pragma unroll
             for (int r = 0; r < SL; ++r) {
-                const bool fire = (bal[r] >> lane) & 1ull;
+                // (the mask itself becomes the execution mask: no per-lane bit test)
+                const bool fire = REFM ? __builtin_amdgcn_inverse_ballot_w64(bal[r]) : (bool)((bal[r] >> lane) & 1ull);
                 if (fire) {
                     const int rank = nspk + lane_rank(bal[r]);
                     const uint16_t me = (uint16_t)((w * SL + r) * 64 + lane);
@@ -485,35 +508,49 @@ __global__ __launch_bounds__(WPC * 64) LSM_DENSE_VGPR_ATTR void lif_dense_kernel
 
 typedef void (*dense_fn_t)(const DenseArgs);
 
-template <int SL, int INMODE>
+// REFM needs 2 x 2 scalar registers per slot: offered up to 4 slots per lane (the layouts of N <= 4096 with >= 4
+// waves, i.e. every reservoir the dense rows serve by default); fatter layouts keep the countdown in vector registers.
+constexpr int DENSE_REFM_MAX_SL = 4;
+constexpr int DENSE_REFM_REFRACTORY = 2;        // the one period the mask form is written for (the reference's)
+
+template <int SL, int INMODE, bool REFM>
 dense_fn_t pick_dense_wpc(int wpc)
 {
     switch (wpc) {
-    case 1: return lif_dense_kernel<SL, 1, INMODE>;
-    case 2: return lif_dense_kernel<SL, 2, INMODE>;
-    case 4: return lif_dense_kernel<SL, 4, INMODE>;
-    case 8: return lif_dense_kernel<SL, 8, INMODE>;
-    case 16: return lif_dense_kernel<SL, 16, INMODE>;
+    case 1: return lif_dense_kernel<SL, 1, INMODE, REFM>;
+    case 2: return lif_dense_kernel<SL, 2, INMODE, REFM>;
+    case 4: return lif_dense_kernel<SL, 4, INMODE, REFM>;
+    case 8: return lif_dense_kernel<SL, 8, INMODE, REFM>;
+    case 16: return lif_dense_kernel<SL, 16, INMODE, REFM>;
     default: return nullptr;
     }
 }
 
 template <int INMODE>
-dense_fn_t pick_dense_sl(int sl, int wpc)
+dense_fn_t pick_dense_sl(int sl, int wpc, bool refm)
 {
+    if (refm && sl <= DENSE_REFM_MAX_SL) {
+        switch (sl) {
+        case 1: return pick_dense_wpc<1, INMODE, true>(wpc);
+        case 2: return pick_dense_wpc<2, INMODE, true>(wpc);
+        case 4: return pick_dense_wpc<4, INMODE, true>(wpc);
+        default: return nullptr;
+        }
+    }
     switch (sl) {
-    case 1: return pick_dense_wpc<1, INMODE>(wpc);
-    case 2: return pick_dense_wpc<2, INMODE>(wpc);
-    case 4: return pick_dense_wpc<4, INMODE>(wpc);
-    case 8: if (INMODE == 2) return nullptr; else return pick_dense_wpc<INMODE == 2 ? 4 : 8, INMODE>(wpc);
-    case 16: if (INMODE == 2) return nullptr; else return pick_dense_wpc<INMODE == 2 ? 4 : 16, INMODE>(wpc);
+    case 1: return pick_dense_wpc<1, INMODE, false>(wpc);
+    case 2: return pick_dense_wpc<2, INMODE, false>(wpc);
+    case 4: return pick_dense_wpc<4, INMODE, false>(wpc);
+    case 8: if (INMODE == 2) return nullptr; else return pick_dense_wpc<INMODE == 2 ? 4 : 8, INMODE, false>(wpc);
+    case 16: if (INMODE == 2) return nullptr; else return pick_dense_wpc<INMODE == 2 ? 4 : 16, INMODE, false>(wpc);
     default: return nullptr;
     }
 }
 
-dense_fn_t pick_dense_0(int sl, int wpc);      // lif_dense_0.hip (INMODE 0: entries from global memory)
-dense_fn_t pick_dense_1(int sl, int wpc);      // lif_dense_1.hip (INMODE 1: entries in registers)
-dense_fn_t pick_dense_2(int sl, int wpc);      // lif_dense_2.hip (INMODE 2: channel masks, C <= 128, SL <= 4)
+// refm: the caller checked a.refractory == DENSE_REFM_REFRACTORY (else the countdown stays in vector registers)
+dense_fn_t pick_dense_0(int sl, int wpc, bool refm);      // lif_dense_0.hip (INMODE 0: entries from global memory)
+dense_fn_t pick_dense_1(int sl, int wpc, bool refm);      // lif_dense_1.hip (INMODE 1: entries in registers)
+dense_fn_t pick_dense_2(int sl, int wpc, bool refm);      // lif_dense_2.hip (INMODE 2: channel masks, C <= 128, SL <= 4)
 #if LSM_STAMP
 int read_lif_stamps_d2(unsigned long long *o, int r);   // stamps of the INMODE-2 unit (the cfg2 kernel)
 #endif

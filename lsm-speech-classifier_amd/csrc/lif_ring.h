@@ -59,8 +59,9 @@ namespace lsm_lif {
 #endif
 
 #ifndef LSM_RING_ABLATE
-#define LSM_RING_ABLATE 0   // diagnostic builds only (1, 2, 8 give WRONG results): 1 = no window loads, 2 = no
-#endif                      // accumulator read-modify-write, 8 = no list loads
+#define LSM_RING_ABLATE 0   // diagnostic builds only (1, 2, 8, 16, 32 give WRONG results): 1 = no window loads, 2 = no
+#endif                      // accumulator read-modify-write, 8 = no list loads, 16 = no input drive, 32 = no feature updates;
+                            // 64 = the input drive issued TWICE, the second pass adding zeros (results stay right: its time is the drive's cost)
 
 struct RingArgs {
     int N, C, T, B;
@@ -226,15 +227,15 @@ __global__ __launch_bounds__(WPC * 64) void lif_ring_kernel(const RingArgs a)
     uint32_t tot_spk = 0u;             // spikes of my wave (stats)
     __syncthreads();
 
-    auto input_drive = [&](int ts) {
+    auto input_drive = [&](int ts, uint32_t keep = 0xFFFFFFFFu) {
         const uint32_t *row = bits + ts * CW;
         if (INREG) {
 #pragma unroll
             for (int q = 0; q < IN_REG_SLOTS; q += 2) {
                 if (q * 64 < a.EinW) {
                     const uint32_t w0 = row[in_word[q]], w1 = row[in_word[q + 1]];
-                    atomicAdd(cnt + in_tgt[q], (w0 & in_mask[q]) ? in_inc[q] : 0u);
-                    if ((q + 1) * 64 < a.EinW) atomicAdd(cnt + in_tgt[q + 1], (w1 & in_mask[q + 1]) ? in_inc[q + 1] : 0u);
+                    atomicAdd(cnt + in_tgt[q], ((w0 & in_mask[q]) ? in_inc[q] : 0u) & keep);
+                    if ((q + 1) * 64 < a.EinW) atomicAdd(cnt + in_tgt[q + 1], ((w1 & in_mask[q + 1]) ? in_inc[q + 1] : 0u) & keep);
                 }
             }
         } else {
@@ -255,7 +256,7 @@ __global__ __launch_bounds__(WPC * 64) void lif_ring_kernel(const RingArgs a)
                         const uint32_t bit = (row[c >> 5] >> (c & 31)) & 1u;
                         const uint32_t i = x[u] & 0xFFFFu;              // target neuron: 16-bit count in word i/2
                         atomicAdd(cnt + (ok ? (uint32_t)ring_cnt_word((int)i) : (uint32_t)lane),
-                                  ok ? bit << ((i & 1u) * 16u) : 0u);
+                                  (ok ? bit << ((i & 1u) * 16u) : 0u) & keep);
                     }
                 }
             }
@@ -433,7 +434,12 @@ __global__ __launch_bounds__(WPC * 64) void lif_ring_kernel(const RingArgs a)
 #undef LSM_RING_READ
 #undef LSM_RING_APPLY
         }
-        input_drive(t);
+        if (!(LSM_RING_ABLATE & 16)) input_drive(t);
+        if (LSM_RING_ABLATE & 64) {
+            uint32_t zero = 0u;
+            asm volatile("" : "+s"(zero));          // opaque: the second pass is not folded away
+            input_drive(t, zero);
+        }
         wave_lds_fence();
         LSM_RING_MARK(4)               // input counts (the fetch of the input-map entries included)
 
@@ -476,7 +482,7 @@ __global__ __launch_bounds__(WPC * 64) void lif_ring_kernel(const RingArgs a)
                         rank += 1;
                         hf |= 1u << r;
                         const int osl = (int)(oref[r] & 0xFFFFu) - 1;
-                        if (osl >= 0) {
+                        if (osl >= 0 && !(LSM_RING_ABLATE & 32)) {
                             uint4 f = feat[osl];
                             uint32_t nf = f.x & 0xFFFFu, bursts = f.x >> 16;
                             uint32_t first = f.y & 0xFFFFu, last = f.y >> 16;

@@ -737,9 +737,16 @@ static int reservoir_run(const lsm_reservoir *h, const uint8_t *spikes_u8, int n
     }
     const Variant *v = plan.v;
     if (plan.kernel == 2) {
-        lsm_lif::dense_fn_t dfn = v->inmask       ? lsm_lif::pick_dense_2(v->sl, v->wpc)
-                                  : lif_inreg(*v) ? lsm_lif::pick_dense_1(v->sl, v->wpc)
-                                                  : lsm_lif::pick_dense_0(v->sl, v->wpc);
+        // the reference's refractory period (2 steps) counts down in scalar lane masks (lif_dense.h, REFM);
+        // LSM_DENSE_NO_REFM (diagnostic builds) keeps the vector-register countdown for same-box A/B runs
+        bool refm = h->refractory == lsm_lif::DENSE_REFM_REFRACTORY;
+#if LSM_EXPERIMENT_HOOKS
+        static const bool no_refm = [] { const char *e = getenv("LSM_DENSE_NO_REFM"); return e && atoi(e) != 0; }();
+        if (no_refm) refm = false;
+#endif
+        lsm_lif::dense_fn_t dfn = v->inmask       ? lsm_lif::pick_dense_2(v->sl, v->wpc, refm)
+                                  : lif_inreg(*v) ? lsm_lif::pick_dense_1(v->sl, v->wpc, refm)
+                                                  : lsm_lif::pick_dense_0(v->sl, v->wpc, refm);
         LSM_REQUIRE(dfn != nullptr, "no dense kernel for SL=%d WPC=%d", v->sl, v->wpc);
         lsm_lif::DenseArgs d;
         d.N = h->N; d.C = h->C; d.T = n_steps; d.B = n_clips;

@@ -103,10 +103,12 @@ def test_bench_stages_and_serial_mode():
     assert "roofline" not in d and d["value"] > 0
 
 
-@pytest.mark.parametrize("config,batch", [("cfg4", "256"), ("cfg5", "64")])
+@pytest.mark.parametrize("config,batch", [("cfg4", "256"), ("cfg5", "512")])
 def test_fractions_of_the_large_configs_stay_within_one(config, batch):
     """The ring-row kernel's gather figures charge a spike the bytes it requests, not the padded table: no fraction
-    of the cfg4 / cfg5 lines exceeds 1 (r03's cfg5 line read 1.22)."""
+    of the cfg4 / cfg5 lines exceeds 1 (r03's cfg5 line read 1.22).  Batches at which SURVEY.md 8(d)'s streamed model
+    is a lower bound at all: T*|W|/B grows without limit as B shrinks, while an event-driven kernel gathers a clip's own
+    rows whatever B is (at 64 clips the model charges cfg5 640 MB per clip)."""
     d = _run("--config", config, "--batch", batch, "--no-cpu-baseline", "--steps", "3", "--warmup", "1")
     _check_fractions(d)
     r = d["roofline"]
