@@ -51,7 +51,8 @@ struct DenseArgs {
     const float *leak;         // (NPAD)
     const int *oslot;          // (NPAD) output slot or -1
     const uint32_t *in_ent;    // (WPC, EinW) (channel << 16) | target, 0xFFFFFFFF = padding
-    const uint32_t *inmask;    // (NPAD, 4) input-channel bit mask per neuron (INMODE 2: C <= 128), or null
+    const uint32_t *inmask;    // (NPAD, 4) input-channel bit mask per neuron (INMODE 2, 3: C <= 128), or null
+    const uint8_t *inperm;     // (C) bit position of channel c in the input bit row (INMODE 3), or null (position c)
     int n_keys;
     int key_ids[8];
     float *features;           // (B, n_keys * n_out)
@@ -67,6 +68,9 @@ struct DenseArgs {
 //   2  every neuron holds the bit mask of its input channels in registers (C <= 128, SL <= 4) and counts
 //      popcount(mask & row) against the step's wave-uniform input bit row: no atomics, no count array,
 //      and nothing to wait for between the recurrent rows and the update
+//   3  as 2, with the channels' bit positions permuted (DenseArgs::inperm, chosen by the host) so that the channels
+//      feeding one neuron differ in their position mod 32: the four masked words of a neuron are disjoint and ONE
+//      popcount of their union counts them -- 5 vector instructions per neuron and step instead of 9
 // (Ring-like reservoirs whose dense table no longer fits the caches run on lif_ring.h instead: window + list rows.)
 // LSM_DENSE_MAX_VGPR: register cap of the kernel (0 = the compiler's choice).  Inside the pipeline a reservoir wave
 // shares its SIMD with a front-end wave of 160-168 registers: at <= 112 registers THREE reservoir workgroups fit beside
@@ -92,7 +96,8 @@ template <int SL, int WPC, int INMODE, bool REFM>
 __global__ __launch_bounds__(WPC * 64) LSM_DENSE_VGPR_ATTR void lif_dense_kernel(const DenseArgs a)
 {
     constexpr bool INREG = INMODE == 1;
-    constexpr bool INMASK = INMODE == 2;
+    constexpr bool INMASK = INMODE >= 2;
+    constexpr bool INCOL = INMODE == 3;
     constexpr int NPW = SL * 64;
     constexpr int NPAD = NPW * WPC;
     constexpr int NT = WPC * 64;
@@ -134,17 +139,19 @@ __global__ __launch_bounds__(WPC * 64) LSM_DENSE_VGPR_ATTR void lif_dense_kernel
                 if (v == 0) continue;
                 const int c = (q * 4) / T;
                 const int t0 = (q * 4) - c * T;
-                const uint32_t bit = 1u << (c & 31);
+                const int pc = INCOL ? (int)a.inperm[c] : c;        // the channel's place in the bit row
+                const uint32_t bit = 1u << (pc & 31);
 #pragma unroll
                 for (int k = 0; k < 4; ++k)
-                    if ((v >> (8 * k)) & 0xFFu) atomicOr(&bits[(t0 + k) * CW + (c >> 5)], bit);
+                    if ((v >> (8 * k)) & 0xFFu) atomicOr(&bits[(t0 + k) * CW + (pc >> 5)], bit);
             }
         } else {
             const int nb = a.C * T;
             for (int q = tid; q < nb; q += NT)
                 if (clip[q]) {
                     const int c = q / T;
-                    atomicOr(&bits[(q - c * T) * CW + (c >> 5)], 1u << (c & 31));
+                    const int pc = INCOL ? (int)a.inperm[c] : c;
+                    atomicOr(&bits[(q - c * T) * CW + (pc >> 5)], 1u << (pc & 31));
                 }
         }
     }
@@ -373,7 +380,15 @@ __global__ __launch_bounds__(WPC * 64) LSM_DENSE_VGPR_ATTR void lif_dense_kernel
         for (int r = 0; r < SL; ++r) {
             const int i = (w * SL + r) * 64 + lane;
             uint32_t nin;
-            if (INMASK) {
+            if (INCOL) {
+                // disjoint by construction of the bit positions: the union's popcount is the sum of the four.
+                // (v_and_or_b32 spelled out: the compiler forms four v_and and two v_or/v_or3 from the C expression)
+                uint32_t u = im[r][0] & rowbits[0];
+#pragma unroll
+                for (int q = 1; q < 4; ++q)
+                    asm("v_and_or_b32 %0, %1, %2, %0" : "+v"(u) : "v"(im[r][q]), "s"(rowbits[q]));
+                nin = __popc(u);
+            } else if (INMASK) {
                 nin = __popc(im[r][0] & rowbits[0]) + __popc(im[r][1] & rowbits[1]) +
                       __popc(im[r][2] & rowbits[2]) + __popc(im[r][3] & rowbits[3]);
             } else {
@@ -541,8 +556,8 @@ dense_fn_t pick_dense_sl(int sl, int wpc, bool refm)
     case 1: return pick_dense_wpc<1, INMODE, false>(wpc);
     case 2: return pick_dense_wpc<2, INMODE, false>(wpc);
     case 4: return pick_dense_wpc<4, INMODE, false>(wpc);
-    case 8: if (INMODE == 2) return nullptr; else return pick_dense_wpc<INMODE == 2 ? 4 : 8, INMODE, false>(wpc);
-    case 16: if (INMODE == 2) return nullptr; else return pick_dense_wpc<INMODE == 2 ? 4 : 16, INMODE, false>(wpc);
+    case 8: if (INMODE >= 2) return nullptr; else return pick_dense_wpc<INMODE >= 2 ? 4 : 8, INMODE, false>(wpc);
+    case 16: if (INMODE >= 2) return nullptr; else return pick_dense_wpc<INMODE >= 2 ? 4 : 16, INMODE, false>(wpc);
     default: return nullptr;
     }
 }
@@ -551,8 +566,10 @@ dense_fn_t pick_dense_sl(int sl, int wpc, bool refm)
 dense_fn_t pick_dense_0(int sl, int wpc, bool refm);      // lif_dense_0.hip (INMODE 0: entries from global memory)
 dense_fn_t pick_dense_1(int sl, int wpc, bool refm);      // lif_dense_1.hip (INMODE 1: entries in registers)
 dense_fn_t pick_dense_2(int sl, int wpc, bool refm);      // lif_dense_2.hip (INMODE 2: channel masks, C <= 128, SL <= 4)
+dense_fn_t pick_dense_3(int sl, int wpc, bool refm);      // lif_dense_3.hip (INMODE 3: channel masks at coloured positions)
 #if LSM_STAMP
-int read_lif_stamps_d2(unsigned long long *o, int r);   // stamps of the INMODE-2 unit (the cfg2 kernel)
+int read_lif_stamps_d2(unsigned long long *o, int r);   // stamps of the INMODE-2 unit
+int read_lif_stamps_d3(unsigned long long *o, int r);   // stamps of the INMODE-3 unit (the cfg2 kernel)
 #endif
 
 }  // namespace lsm_lif

@@ -76,7 +76,7 @@ struct RingArgs {
     const uint2 *rem;          // list entries {LDS byte offset of the target's accumulator, weight bits}
     const float *leak;         // (NPAD), neuron order
     const int *oslot;          // (NPAD) output slot or -1, neuron order
-    const uint32_t *in_ent;    // (WPC, EinW) (channel << 16) | target neuron, 0xFFFFFFFF = padding
+    const uint32_t *in_ent;    // (WPC, EinW) packed entries (ring_pack_entry), EinW a multiple of RING_ENT_BLOCK, 0 = padding
     int n_keys;
     int key_ids[8];
     float *features;           // (B, n_keys * n_out)
@@ -93,6 +93,20 @@ typedef uint32_t ring_u2 __attribute__((ext_vector_type(2)));
 constexpr int RING_DUMP_WORDS = 64;                 // LDS words 0..63 of an array: where idle lanes add their zeros
 constexpr int RING_MAX_QUADS = 32;                  // 8192 neurons
 
+// Input-map entries of the ring kernel, one packed word per (channel c -> target neuron i) pair, built by the host:
+//   bits  0..14  byte offset of i's 16-bit count from the start of the count array (its dump words included)
+//   bit   15     i & 1: the count sits in the upper half of its word
+//   bits 16..20  c & 31, bits 21..31  c >> 5: where the channel's bit sits in the step's input bit row
+// A wave's entries are padded to whole blocks of RING_ENT_BLOCK with zeros: a zero entry adds channel 0's bit to dump
+// word 0, which nobody reads -- so the drive runs without guards, exec masks or branches.
+constexpr int RING_ENT_BLOCK = 512;                 // entries per block: 8 per lane
+constexpr int RING_ENT_REG_BLOCKS = 1;              // blocks a wave keeps resident in registers (INREG): 8 registers
+__host__ __device__ inline uint32_t ring_pack_entry(int c, int i)
+{
+    return (uint32_t)((RING_DUMP_WORDS + (i >> 1)) * 4) | ((uint32_t)(i & 1) << 15) | ((uint32_t)(c & 31) << 16) |
+           ((uint32_t)(c >> 5) << 21);
+}
+
 // owner of quad g in a layout: (wave, register quad)
 __host__ __device__ inline int ring_wave_of_quad(int g, int ql, int wpc, bool strided) { return strided ? g % wpc : g / ql; }
 __host__ __device__ inline int ring_slot_of_quad(int g, int ql, int wpc, bool strided) { return strided ? g / wpc : g % ql; }
@@ -103,10 +117,14 @@ __host__ __device__ inline int ring_acc_word(int i) { return RING_DUMP_WORDS + i
 // input counts: 16 bits per neuron, two neurons per word, behind their own dump words
 __host__ __device__ inline int ring_cnt_word(int i) { return RING_DUMP_WORDS + (i >> 1); }
 
-// QL: quads (256 neurons, 4 per lane) per wave; WPC: waves per clip; INREG: the wave's input-map entries sit
-// in registers (else they stream from global memory every step); STRIDED: quad ownership (see above).
+// QL: quads (256 neurons, 4 per lane) per wave; WPC: waves per clip; INREG: the wave's input-map entries (at most
+// RING_ENT_REG_BLOCKS blocks of 512, one packed word each) stay in registers, else they stream from global memory
+// every step; STRIDED: quad ownership (see above).
+// (Up to two quads per wave the strided kernel must keep four waves per SIMD -- 128 registers -- whatever it holds in
+// registers: two clips per CU is what its LDS image allows, and that is 16 waves.)
 template <int QL, int WPC, bool INREG, bool STRIDED>
-__global__ __launch_bounds__(WPC * 64) void lif_ring_kernel(const RingArgs a)
+__global__ __launch_bounds__(WPC * 64) __attribute__((amdgpu_waves_per_eu((QL <= 2 && STRIDED) ? 4 : 1)))
+void lif_ring_kernel(const RingArgs a)
 {
     constexpr int SL = 4 * QL;
     constexpr int NQP = QL * WPC;                   // quads of the padded layout (<= 32)
@@ -193,23 +211,14 @@ __global__ __launch_bounds__(WPC * 64) void lif_ring_kernel(const RingArgs a)
         }
     }
     const uint32_t ref_set = (uint32_t)a.refractory << 16;
-    uint32_t in_word[IN_REG_SLOTS], in_mask[IN_REG_SLOTS], in_tgt[IN_REG_SLOTS], in_inc[IN_REG_SLOTS];
+    const float theta = a.theta, w_in = a.w_in;
+    const uint32_t *my_ent = a.in_ent + (size_t)w * a.EinW;            // EinW: a multiple of RING_ENT_BLOCK
+    constexpr int EPL = RING_ENT_BLOCK / 64;                            // entries per lane and block
+    uint32_t ent_reg[INREG ? EPL * RING_ENT_REG_BLOCKS : 1];            // INREG: the wave's whole map, resident
     if (INREG) {
 #pragma unroll
-        for (int q = 0; q < IN_REG_SLOTS; ++q) {
-            const int e = q * 64 + lane;
-            const uint32_t x = e < a.EinW ? a.in_ent[(size_t)w * a.EinW + e] : 0xFFFFFFFFu;
-            const bool ok = x != 0xFFFFFFFFu;
-            const uint32_t c = x >> 16;
-            const uint32_t i = x & 0xFFFFu;                             // target neuron
-            in_word[q] = ok ? (c >> 5) : 0u;
-            in_mask[q] = ok ? (1u << (c & 31)) : 0u;
-            in_inc[q] = 1u << ((i & 1u) * 16u);                         // the target's half of its count word
-            in_tgt[q] = ok ? (uint32_t)ring_cnt_word((int)i) : (uint32_t)lane;   // padding: own dump word, adds 0
-        }
+        for (int u = 0; u < EPL * RING_ENT_REG_BLOCKS; ++u) ent_reg[u] = my_ent[u * 64 + lane];
     }
-    const float theta = a.theta, w_in = a.w_in;
-    const uint32_t *my_ent = a.in_ent + (size_t)w * a.EinW;
     const bool trace = a.spike_matrix != nullptr || a.v_trace != nullptr;
     // byte address (from the start of LDS) of my four accumulators of global quad g: acc_b + g*1024
     const uint32_t acc_b = (uint32_t)RING_DUMP_WORDS * 4u + (uint32_t)lane * 16u;
@@ -227,38 +236,40 @@ __global__ __launch_bounds__(WPC * 64) void lif_ring_kernel(const RingArgs a)
     uint32_t tot_spk = 0u;             // spikes of my wave (stats)
     __syncthreads();
 
+    // Input drive of step `ts`: every entry looks its channel up in the step's bit row and adds the bit to its target's
+    // 16-bit count (integer LDS atomics: two entries of one instruction may share a target).  One block = 8 entries
+    // per lane, straight-line: the 8 row-word reads are in flight together, then the 8 atomics -- the first version
+    // read, waited and added entry by entry behind per-entry guards, and a same-box build that issued the drive twice
+    // put it at 1.49 of cfg4's 6.44 ms (profiles/r04_ring_input_drive.txt).  A wave's entries only ever touch the counts
+    // of its own neurons, which it cleared itself in the previous update: the drive needs no barrier and runs at the TOP
+    // of the step, so its LDS round trips overlap the spike-list set-up and the first row loads.
+    auto drive_block = [&](const uint32_t *row, const uint32_t (&x)[EPL], uint32_t keep) __attribute__((always_inline)) {
+        uint32_t rw[EPL];
+#pragma unroll
+        for (int u = 0; u < EPL; ++u) rw[u] = row[x[u] >> 21];
+#pragma unroll
+        for (int u = 0; u < EPL; ++u) {
+            const uint32_t bit = (rw[u] >> ((x[u] >> 16) & 31u)) & 1u;
+            const uint32_t inc = (bit << ((x[u] >> 11) & 16u)) & keep;
+            atomicAdd(reinterpret_cast<uint32_t *>(reinterpret_cast<unsigned char *>(cnt) + (x[u] & 0x7FFFu)), inc);
+        }
+    };
     auto input_drive = [&](int ts, uint32_t keep = 0xFFFFFFFFu) {
         const uint32_t *row = bits + ts * CW;
         if (INREG) {
 #pragma unroll
-            for (int q = 0; q < IN_REG_SLOTS; q += 2) {
-                if (q * 64 < a.EinW) {
-                    const uint32_t w0 = row[in_word[q]], w1 = row[in_word[q + 1]];
-                    atomicAdd(cnt + in_tgt[q], ((w0 & in_mask[q]) ? in_inc[q] : 0u) & keep);
-                    if ((q + 1) * 64 < a.EinW) atomicAdd(cnt + in_tgt[q + 1], ((w1 & in_mask[q + 1]) ? in_inc[q + 1] : 0u) & keep);
-                }
+            for (int q = 0; q < RING_ENT_REG_BLOCKS; ++q) {
+                uint32_t x[EPL];
+#pragma unroll
+                for (int u = 0; u < EPL; ++u) x[u] = ent_reg[q * EPL + u];
+                drive_block(row, x, keep);
             }
         } else {
-            // eight entries per lane are fetched together (one L2 round trip per 512 entries instead of one per
-            // 64); a padding entry counts 0 into the lane's own dump word, so nothing is masked off
-            for (int e0 = 0; e0 < a.EinW; e0 += 512) {
-                uint32_t x[8];
+            for (int e0 = 0; e0 < a.EinW; e0 += RING_ENT_BLOCK) {
+                uint32_t x[EPL];
 #pragma unroll
-                for (int u = 0; u < 8; ++u) {
-                    const int e = e0 + u * 64 + lane;
-                    x[u] = e < a.EinW ? my_ent[e] : 0xFFFFFFFFu;
-                }
-#pragma unroll
-                for (int u = 0; u < 8; ++u) {
-                    if (e0 + u * 64 < a.EinW) {                     // wave-uniform
-                        const bool ok = x[u] != 0xFFFFFFFFu;
-                        const uint32_t c = ok ? (x[u] >> 16) : 0u;
-                        const uint32_t bit = (row[c >> 5] >> (c & 31)) & 1u;
-                        const uint32_t i = x[u] & 0xFFFFu;              // target neuron: 16-bit count in word i/2
-                        atomicAdd(cnt + (ok ? (uint32_t)ring_cnt_word((int)i) : (uint32_t)lane),
-                                  (ok ? bit << ((i & 1u) * 16u) : 0u) & keep);
-                    }
-                }
+                for (int u = 0; u < EPL; ++u) x[u] = my_ent[e0 + u * 64 + lane];
+                drive_block(row, x, keep);
             }
         }
     };
@@ -270,6 +281,15 @@ __global__ __launch_bounds__(WPC * 64) void lif_ring_kernel(const RingArgs a)
         const int cur = t & 1, prv = cur ^ 1;
         const uint16_t *list_prev = wlist + prv * NPAD;
         uint16_t *list_cur = wlist + cur * NPAD;
+
+        // ---- input drive first (independent of the rows; see input_drive) ----
+        if (!(LSM_RING_ABLATE & 16)) input_drive(t);
+        if (LSM_RING_ABLATE & 64) {
+            uint32_t zero = 0u;
+            asm volatile("" : "+s"(zero));          // opaque: the second pass is not folded away
+            input_drive(t, zero);
+        }
+        LSM_RING_MARK(4)               // input counts issued (the fetch of streamed input-map entries included)
 
         // ---- spiking neurons of step t-1: prefix of the per-quad counts, lane l <- l-th neuron ----
         const uint32_t cv = wcnt[prv * 32 + (lane & 31)];
@@ -434,14 +454,7 @@ __global__ __launch_bounds__(WPC * 64) void lif_ring_kernel(const RingArgs a)
 #undef LSM_RING_READ
 #undef LSM_RING_APPLY
         }
-        if (!(LSM_RING_ABLATE & 16)) input_drive(t);
-        if (LSM_RING_ABLATE & 64) {
-            uint32_t zero = 0u;
-            asm volatile("" : "+s"(zero));          // opaque: the second pass is not folded away
-            input_drive(t, zero);
-        }
         wave_lds_fence();
-        LSM_RING_MARK(4)               // input counts (the fetch of the input-map entries included)
 
         // ---- neuron update, quad by quad: leak/integrate/threshold by select, then (only if a neuron of the
         //      quad fired) its entries of the quad's spike list and the feature accumulators ----

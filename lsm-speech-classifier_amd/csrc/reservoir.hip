@@ -46,6 +46,7 @@ struct Variant {            // per waves-per-clip layout
     int *oslot = nullptr;
     uint32_t *in_ent = nullptr;
     uint32_t *inmask = nullptr;      // (npad, 4) input-channel masks, only when C <= 128 and sl <= 4
+    bool incol = false;              // the masks use the coloured bit positions of lsm_reservoir::inperm (INMODE 3)
 };
 
 struct RingVariant {        // per waves-per-clip layout of the ring-row kernel (lif_ring.h)
@@ -89,6 +90,10 @@ struct lsm_reservoir {
     uint32_t band_pitch = 0;
     double band_bytes_sum = 0;       // sum over rows of the window bytes that exist (what a spike's window loads can touch)
     int band_h = 0, band_nq = 0, band_wsq = 0;
+    // INMODE 3 of the dense kernel: bit position of every input channel in the step's input bit row such that the
+    // channels feeding one neuron sit at different positions mod 32 (colour_input_channels); null when no such
+    // assignment was found (then the masks keep the natural positions, INMODE 2)
+    uint8_t *inperm = nullptr;
     int mode = 0;           // 0 auto, 1 sparse (CSC scatter through LDS), 2 dense rows, 3 ring rows,
                             // 4 ring rows with contiguous quad ownership only (tests)
     Variant var[5];         // wpc = 1, 2, 4, 8, 16 (wpc == 0: not available)
@@ -102,6 +107,7 @@ static int free_reservoir(lsm_reservoir *h)
     if (h->rowptr) (void)hipFree(h->rowptr);
     if (h->wt) (void)hipFree(h->wt);
     if (h->band) (void)hipFree(h->band);
+    if (h->inperm) (void)hipFree(h->inperm);
     for (auto &v : h->var) {
         if (v.seg) (void)hipFree(v.seg);
         if (v.segoff) (void)hipFree(v.segoff);
@@ -171,6 +177,82 @@ static int upload(T **dst, const std::vector<T> &src)
     return LSM_OK;
 }
 
+// Bit positions for the input channels of the dense kernel's INMODE 3 (C <= 128): position p = word * 32 + bit with
+// word < ceil(C / 32), such that the channels feeding ONE neuron all have different `bit`s.  Then the words
+// (mask_w & row_w) of a neuron have no set bit in common and popcount(m0&r0) + ... + popcount(m3&r3) =
+// popcount((m0&r0) | (m1&r1) | (m2&r2) | (m3&r3)): one v_and, three v_and_or and one v_bcnt per neuron and step
+// instead of four v_and, four v_bcnt and an add.  This is an equitable colouring of the channels' conflict graph
+// (two channels conflict when they share a target) with 32 colours of ceil(C/32) places each; greedy by conflict
+// degree with a one-move repair finds one for every input map tried (N = 256..4000, C = 32..128).  Returns false
+// when it does not: the caller keeps the natural positions (INMODE 2).
+static bool colour_input_channels(int N, int C, const int32_t *in_tgt, int in_fanout, std::vector<uint8_t> *perm)
+{
+    if (C > 128) return false;
+    const int cap = (C + 31) / 32;
+    std::vector<std::vector<int>> chans_of(N);
+    for (int c = 0; c < C; ++c)
+        for (int d = 0; d < in_fanout; ++d) chans_of[in_tgt[(size_t)c * in_fanout + d]].push_back(c);
+    std::vector<std::vector<char>> adj(C, std::vector<char>(C, 0));
+    std::vector<int> deg(C, 0);
+    for (const auto &l : chans_of)
+        for (int x : l)
+            for (int y : l)
+                if (x != y && !adj[x][y]) { adj[x][y] = 1; ++deg[x]; }
+    std::vector<int> order(C);
+    for (int c = 0; c < C; ++c) order[c] = c;
+    std::stable_sort(order.begin(), order.end(), [&](int x, int y) { return deg[x] > deg[y]; });
+    std::vector<int> col(C, -1), cnt(32, 0);
+    auto used_by_neighbours = [&](int c, int skip) {
+        uint32_t used = 0u;
+        for (int y = 0; y < C; ++y)
+            if (adj[c][y] && col[y] >= 0 && y != skip) used |= 1u << col[y];
+        return used;
+    };
+    for (int c : order) {
+        const uint32_t used = used_by_neighbours(c, -1);
+        int best = -1;
+        for (int k = 0; k < 32; ++k)
+            if (!((used >> k) & 1u) && cnt[k] < cap && (best < 0 || cnt[k] < cnt[best])) best = k;
+        if (best < 0) {
+            // every colour free of c's neighbours is full: move one member of such a colour elsewhere
+            for (int k = 0; k < 32 && best < 0; ++k) {
+                if ((used >> k) & 1u) continue;
+                for (int v = 0; v < C && best < 0; ++v) {
+                    if (col[v] != k) continue;
+                    const uint32_t uv = used_by_neighbours(v, -1);
+                    for (int q = 0; q < 32; ++q)
+                        if (q != k && !((uv >> q) & 1u) && cnt[q] < cap && !adj[v][c]) {
+                            col[v] = q; ++cnt[q]; --cnt[k];
+                            best = k;
+                            break;
+                        }
+                }
+            }
+            if (best < 0) return false;
+        }
+        col[c] = best;
+        ++cnt[best];
+    }
+    // place the members of a colour in different words; verify before trusting the result
+    perm->assign(C, 0);
+    std::vector<int> next(32, 0);
+    for (int c = 0; c < C; ++c) (*perm)[c] = (uint8_t)(next[col[c]]++ * 32 + col[c]);
+    for (const auto &l : chans_of) {
+        uint32_t seen = 0u;
+        for (int x : l) {
+            const uint32_t bit = 1u << ((*perm)[x] & 31);
+            if (seen & bit) return false;
+            seen |= bit;
+        }
+    }
+    std::vector<char> taken(cap * 32, 0);
+    for (int c = 0; c < C; ++c) {
+        if ((*perm)[c] >= cap * 32 || taken[(*perm)[c]]) return false;
+        taken[(*perm)[c]] = 1;
+    }
+    return true;
+}
+
 extern "C" __attribute__((visibility("default")))
 int lsm_reservoir_create(lsm_reservoir **out, int num_neurons, int n_channels,
                          const int32_t *csc_ptr, const int32_t *csc_post, const float *csc_w,
@@ -224,6 +306,16 @@ int lsm_reservoir_create(lsm_reservoir **out, int num_neurons, int n_channels,
     if (rc) { free_reservoir(h); return rc; }
     std::vector<uint32_t> rowptr(csc_ptr, csc_ptr + N + 1);
     if ((rc = upload(&h->rowptr, rowptr))) { free_reservoir(h); return rc; }
+
+    // coloured bit positions for the input masks of the dense kernel (one assignment per reservoir)
+    std::vector<uint8_t> inperm;
+#if LSM_EXPERIMENT_HOOKS
+    static const bool no_incol = [] { const char *e = getenv("LSM_DENSE_NO_INCOL"); return e && atoi(e) != 0; }();
+#else
+    constexpr bool no_incol = false;
+#endif
+    const bool coloured = !no_incol && colour_input_channels(N, C, in_tgt, in_fanout, &inperm);
+    if (coloured && (rc = upload(&h->inperm, inperm))) { free_reservoir(h); return rc; }
 
     const int wpcs[5] = {1, 2, 4, 8, 16};
     for (int vi = 0; vi < 5; ++vi) {
@@ -282,14 +374,16 @@ int lsm_reservoir_create(lsm_reservoir **out, int num_neurons, int n_channels,
             for (int c = 0; c < C; ++c)
                 for (int d = 0; d < in_fanout; ++d) {
                     const int tgt = in_tgt[(size_t)c * in_fanout + d];
-                    uint32_t &word = im[(size_t)tgt * 4 + (c >> 5)];
-                    distinct = distinct && !(word & (1u << (c & 31)));
-                    word |= 1u << (c & 31);
+                    const int pc = coloured ? inperm[c] : c;          // bit position of channel c in the input bit row
+                    uint32_t &word = im[(size_t)tgt * 4 + (pc >> 5)];
+                    distinct = distinct && !(word & (1u << (pc & 31)));
+                    word |= 1u << (pc & 31);
                 }
             if (distinct && (rc = upload(&v.inmask, im))) {
                 free_reservoir(h);
                 return rc;
             }
+            v.incol = distinct && coloured;
         }
         v.wpc = wpc; v.sl = sl; v.einw = einw;
     }
@@ -393,16 +487,19 @@ int lsm_reservoir_create(lsm_reservoir **out, int num_neurons, int n_channels,
                     std::vector<int> os(npad, -1);
                     for (int i = 0; i < N; ++i) lk[i] = leak[i];
                     for (int o = 0; o < n_out; ++o) os[out_idx[o]] = o;
+                    // input map per owner wave, packed (lsm_lif::ring_pack_entry), padded with zero entries to whole
+                    // blocks of RING_ENT_BLOCK so that the kernel's drive needs no guards
                     std::vector<std::vector<uint32_t>> per(wpc);
                     for (int c = 0; c < C; ++c)
                         for (int d = 0; d < in_fanout; ++d) {
                             const int tgt = in_tgt[(size_t)c * in_fanout + d];
-                            per[wave_of(tgt)].push_back(((uint32_t)c << 16) | (uint32_t)tgt);
+                            per[wave_of(tgt)].push_back(lsm_lif::ring_pack_entry(c, tgt));
                         }
                     size_t mx = 1;
                     for (auto &pp : per) mx = std::max(mx, pp.size());
-                    const int einw = (int)((mx + 63) / 64 * 64);
-                    std::vector<uint32_t> ent((size_t)wpc * einw, 0xFFFFFFFFu);
+                    const int blk = lsm_lif::RING_ENT_BLOCK;
+                    const int einw = (int)((mx + blk - 1) / blk * blk);
+                    std::vector<uint32_t> ent((size_t)wpc * einw, 0u);
                     for (int w = 0; w < wpc; ++w)
                         std::copy(per[w].begin(), per[w].end(), ent.begin() + (size_t)w * einw);
                     RingVariant &v = h->rvar[vi];
@@ -711,7 +808,13 @@ static int reservoir_run(const lsm_reservoir *h, const uint8_t *spikes_u8, int n
     }
     if (plan.kernel == 3) {
         const RingVariant *rv = plan.rv;
-        const bool inreg = rv->einw <= IN_REG_SLOTS * 64;
+        // the wave's input map stays in registers when it is one block (8 registers) AND the layout has few neurons per
+        // lane: with three or four quads per wave the extra registers would cost a wave per SIMD
+        bool inreg = rv->einw <= lsm_lif::RING_ENT_BLOCK * lsm_lif::RING_ENT_REG_BLOCKS && rv->ql <= 2 && rv->strided;
+#if LSM_EXPERIMENT_HOOKS
+        static const bool no_inreg = [] { const char *e = getenv("LSM_RING_NO_INREG"); return e && atoi(e) != 0; }();
+        if (no_inreg) inreg = false;
+#endif
         lsm_lif::ring_fn_t rfn = rv->ql == 1   ? lsm_lif::pick_ring_1(rv->wpc, inreg, rv->strided)
                                  : rv->ql == 2 ? lsm_lif::pick_ring_2(rv->wpc, inreg, rv->strided)
                                  : rv->ql == 3 ? lsm_lif::pick_ring_3(rv->wpc, inreg, rv->strided)
@@ -744,7 +847,8 @@ static int reservoir_run(const lsm_reservoir *h, const uint8_t *spikes_u8, int n
         static const bool no_refm = [] { const char *e = getenv("LSM_DENSE_NO_REFM"); return e && atoi(e) != 0; }();
         if (no_refm) refm = false;
 #endif
-        lsm_lif::dense_fn_t dfn = v->inmask       ? lsm_lif::pick_dense_2(v->sl, v->wpc, refm)
+        lsm_lif::dense_fn_t dfn = v->inmask       ? (v->incol ? lsm_lif::pick_dense_3(v->sl, v->wpc, refm)
+                                                              : lsm_lif::pick_dense_2(v->sl, v->wpc, refm))
                                   : lif_inreg(*v) ? lsm_lif::pick_dense_1(v->sl, v->wpc, refm)
                                                   : lsm_lif::pick_dense_0(v->sl, v->wpc, refm);
         LSM_REQUIRE(dfn != nullptr, "no dense kernel for SL=%d WPC=%d", v->sl, v->wpc);
@@ -755,6 +859,7 @@ static int reservoir_run(const lsm_reservoir *h, const uint8_t *spikes_u8, int n
         d.theta = h->theta; d.w_in = h->w_in;
         d.raster = spikes_u8; d.wt = h->wt; d.leak = v->leak; d.oslot = v->oslot; d.in_ent = v->in_ent;
         d.inmask = v->inmask;
+        d.inperm = v->incol ? h->inperm : nullptr;
         d.n_keys = n_keys;
         for (int k = 0; k < 8; ++k) d.key_ids[k] = k < n_keys ? key_ids[k] : 0;
         d.features = features_out; d.spike_matrix = spike_matrix_out; d.v_trace = v_trace_out;
@@ -886,9 +991,10 @@ int lsm_debug_lif_stamps(unsigned long long *out8, int reset)
 {
     for (int k = 0; k < 8; ++k) out8[k] = 0;
 #if LSM_STAMP
-    for (int q = 0; q < 5; ++q) {                 // the four sparse-kernel units + the dense kernel's INMODE-2 unit
+    for (int q = 0; q < 6; ++q) {                 // the four sparse-kernel units + the dense kernel's INMODE-2 and -3 units
         unsigned long long part[8];
-        int rc = q < 4 ? lsm_lif::read_lif_stamps(q, part, reset) : lsm_lif::read_lif_stamps_d2(part, reset);
+        int rc = q < 4 ? lsm_lif::read_lif_stamps(q, part, reset)
+                       : (q == 4 ? lsm_lif::read_lif_stamps_d2(part, reset) : lsm_lif::read_lif_stamps_d3(part, reset));
         if (rc) return rc;
         for (int k = 0; k < 8; ++k) out8[k] += part[k];
     }

@@ -164,6 +164,7 @@ def test_bench_rccl_code_path_with_one_rank():
     env = dict(os.environ, RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
                LSM_BENCH_FORCE_DIST="1")
     env.pop("LSM_BENCH_BACKEND", None)
+    env.pop("GPU_MAX_HW_QUEUES", None)        # this process's package import set 12; a fresh process under a launcher chooses
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "6", "--warmup", "2",
                         "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=600)
     assert p.returncode == 0, p.stderr[-3000:]
