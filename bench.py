@@ -94,6 +94,9 @@ def parse_args(argv=None):
                          "(what the product does per split, extract_lsm_features.py, where it is negligible); "
                          "'per-step' = an all-gather behind every step's reservoir kernel")
     ap.add_argument("--exchange-chunk", type=int, default=5, help="steps per all-gather of the chunked exchange")
+    ap.add_argument("--tail-steps", type=int, default=None,
+                    help="the last this-many timed steps are submitted with HotPath.submit(tail=True), as HotPath.run() does "
+                         "for the last batches of a finite list (default: the pipeline's TAIL_STEPS; 0 = none)")
     ap.add_argument("--no-unprimed", action="store_true",
                     help="skip the first, unprimed pass (one step per stream, W warm-up steps, K timed steps: the "
                          "round-2 protocol) whose figure the line reports as `unprimed` beside the headline")
@@ -277,7 +280,8 @@ def run_rank(args):
     dev = torch.device("cuda", local_rank if use_dist else 0)
 
     from lsm_speech_classifier_amd import frontend, reservoir, snn
-    from lsm_speech_classifier_amd.pipeline import HotPath, DEFAULT_STREAMS
+    from lsm_speech_classifier_amd.pipeline import HotPath, DEFAULT_STREAMS, TAIL_STEPS
+    tail_steps = TAIL_STEPS if args.tail_steps is None else max(0, args.tail_steps)
     cfg = CONFIGS[args.config]
     B = args.batch or cfg["batch"]
     fe = frontend.SpikeFrontEnd(cfg["n_filters"], cfg["filterbank"], device=dev)
@@ -342,12 +346,12 @@ def run_rank(args):
                 xs.wait_event(ev)
             gather_chunk(c0, c1)
 
-    def step(i, n_exchanged=0):
+    def step(i, n_exchanged=0, tail=False):
         """One pass of the hot path over the batch on the next stream of the rotation (HotPath.submit, also for
         the --stage variants).  `n_exchanged`: steps of this phase whose rows take part in the exchange."""
         slot = hp._step % hp.n_streams
         out_rows = local_rows[i] if local_rows is not None else None
-        feats, st = hp.submit(stage_in, out=out_rows, stage=args.stage)
+        feats, st = hp.submit(stage_in, out=out_rows, stage=args.stage, tail=tail)
         if gather_bufs is not None:
             # RCCL's stream is ordered after this step's reservoir kernel and the step's stream after the
             # gather; with >= 12 hardware queues the exchange does not disturb the other steps in flight
@@ -403,7 +407,7 @@ def run_rank(args):
         t0 = time.perf_counter()
         out = None
         for i in range(args.steps):
-            out = step(i, args.steps)
+            out = step(i, args.steps, tail=i >= args.steps - tail_steps)   # what HotPath.run() does for a finite list
         enqueue_ms = (time.perf_counter() - t0) / args.steps * 1e3      # host side of a step (asynchronous)
         x_end = finish_exchange(args.steps)                              # inside the timed region, before the fence
         fence()
@@ -510,6 +514,8 @@ def run_rank(args):
                        "streams": hp.n_streams, "fe_streams": hp.n_fe_streams, "hw_queues": hp.hw_queues,
                        "prime": f"{primed_steps} untimed steps (>= {args.prime_ms:g} ms) in HotPath.prime() before the "
                                 f"{args.warmup} warm-up steps",
+                       "tail_steps": f"the last {tail_steps} timed step(s) are submitted with tail=True (low-latency layouts), as "
+                                     f"HotPath.run() submits the last batches of a finite list",
                        "pipeline": ("serial" if hp.n_streams <= 1 else
                                     "pipeline.HotPath: steps rotate over the streams" if not hp.n_fe_streams else
                                     "pipeline.HotPath: front ends on their own streams, reservoir launches behind events"),

@@ -76,7 +76,7 @@ struct RingArgs {
     const uint2 *rem;          // list entries {LDS byte offset of the target's accumulator, weight bits}
     const float *leak;         // (NPAD), neuron order
     const int *oslot;          // (NPAD) output slot or -1, neuron order
-    const uint32_t *in_ent;    // (WPC, EinW) packed entries (ring_pack_entry), EinW a multiple of RING_ENT_BLOCK, 0 = padding
+    const uint32_t *in_ent;    // (WPC, EinW) packed entries (ring_pack_entry), EinW a multiple of RING_ENT_BLOCK, padded with dump-word entries
     int n_keys;
     int key_ids[8];
     float *features;           // (B, n_keys * n_out)
@@ -97,8 +97,9 @@ constexpr int RING_MAX_QUADS = 32;                  // 8192 neurons
 //   bits  0..14  byte offset of i's 16-bit count from the start of the count array (its dump words included)
 //   bit   15     i & 1: the count sits in the upper half of its word
 //   bits 16..20  c & 31, bits 21..31  c >> 5: where the channel's bit sits in the step's input bit row
-// A wave's entries are padded to whole blocks of RING_ENT_BLOCK with zeros: a zero entry adds channel 0's bit to dump
-// word 0, which nobody reads -- so the drive runs without guards, exec masks or branches.
+// A wave's entries are padded to whole blocks of RING_ENT_BLOCK: the padding entry at index e adds channel 0's bit to dump
+// word e % 64 (= its lane's own dump word, which nobody reads) -- so the drive runs without guards, exec masks or
+// branches, and without two padding lanes ever adding to the same word.
 constexpr int RING_ENT_BLOCK = 512;                 // entries per block: 8 per lane
 constexpr int RING_ENT_REG_BLOCKS = 1;              // blocks a wave keeps resident in registers (INREG): 8 registers
 __host__ __device__ inline uint32_t ring_pack_entry(int c, int i)

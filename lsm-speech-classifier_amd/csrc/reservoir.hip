@@ -499,7 +499,10 @@ int lsm_reservoir_create(lsm_reservoir **out, int num_neurons, int n_channels,
                     for (auto &pp : per) mx = std::max(mx, pp.size());
                     const int blk = lsm_lif::RING_ENT_BLOCK;
                     const int einw = (int)((mx + blk - 1) / blk * blk);
-                    std::vector<uint32_t> ent((size_t)wpc * einw, 0u);
+                    // padding entry at index e: channel 0 into dump word e % 64 -- every lane its OWN dump word (64 lanes
+                    // adding to one LDS word serialise: zero-padding cost cfg4 5 ms, profiles/r04_ring_input_drive.txt)
+                    std::vector<uint32_t> ent((size_t)wpc * einw);
+                    for (size_t e = 0; e < ent.size(); ++e) ent[e] = (uint32_t)((e % 64) * 4);
                     for (int w = 0; w < wpc; ++w)
                         std::copy(per[w].begin(), per[w].end(), ent.begin() + (size_t)w * einw);
                     RingVariant &v = h->rvar[vi];

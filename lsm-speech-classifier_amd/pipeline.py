@@ -30,6 +30,9 @@ DEFAULT_STREAMS = 6
 DEFAULT_FE_STREAMS = int(os.environ.get("LSM_FE_STREAMS", "5"))
 DEFAULT_HW_QUEUES = 12
 RASTER_DEPTH = 4                     # raster buffers per front-end stream (two-stage topology)
+# the last batches of a finite list take the low-latency layouts (HotPath.submit(tail=True)); measured at cfg2,
+# 20-step bursts (profiles/r04_tail_steps.txt)
+TAIL_STEPS = int(os.environ.get("LSM_TAIL_STEPS", "1"))
 STAGES = ("full", "frontend", "reservoir")
 
 
@@ -81,6 +84,7 @@ class HotPath:
         # after 1.47 instead of 2.43 ms, and -- what matters for a short burst of steps -- the burst's front ends no
         # longer run in lockstep rounds of four that all end, and all release their reservoir launches, together.
         self.wide_when_idle = os.environ.get("LSM_FE_WIDE_WHEN_IDLE", "1") != "0"
+        self.tail_lone_layout = os.environ.get("LSM_TAIL_LONE_LAYOUT", "1") != "0"   # diagnostic: tail steps' reservoir layout
         self._wide_below = int(os.environ.get("LSM_FE_WIDE_BELOW", "1"))     # diagnostic: front ends in flight below which the wide layout goes out
         self._fe_done = []                  # events of the front ends issued, newest last (two-stage topology)
         # Back-pressure: the host enqueues a step in ~0.1 ms, the GPU runs it in ~0.64: without a bound a long run is
@@ -104,21 +108,23 @@ class HotPath:
         self._h2d = {}
 
     # ---- one step ---------------------------------------------------------------------------
-    def _one(self, x, stats_out, out, stage):
+    def _one(self, x, stats_out, out, stage, tail=False):
         if stage == "frontend":
             return self.fe.encode(x)
         rasters = x if stage == "reservoir" else self.fe.encode(x)
         if self.time_reservoir:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-        feats, _, _ = self.net.run_batch(rasters, self.feature_keys, waves_per_clip=self.waves_per_clip,
+        # a tail step's reservoir launch meets a draining GPU: the layout of a lone launch (more, thinner waves)
+        wpc = 0 if (tail and self.waves_per_clip == -1 and self.tail_lone_layout) else self.waves_per_clip
+        feats, _, _ = self.net.run_batch(rasters, self.feature_keys, waves_per_clip=wpc,
                                          stats_out=stats_out, features_out=out)
         if self.time_reservoir:
             e1.record()
             self.reservoir_events.append((e0, e1))
         return feats
 
-    def submit(self, audio, stats_out=None, after=None, out=None, stage: str = "full"):
+    def submit(self, audio, stats_out=None, after=None, out=None, stage: str = "full", tail: bool = False):
         """Issue one step on the next stream of the rotation.  `audio`: (B, n_samples) float32 -- device tensor,
         or pinned/pageable host tensor / NumPy array, uploaded on the step's own stream.  Returns (features
         (B, n_keys*N_out) device tensor, stream it is produced on); the caller waits (`stream.synchronize()`,
@@ -131,15 +137,20 @@ class HotPath:
         `stage`: "full"; "frontend" (returns the uint8 rasters; `out`/`stats_out` unused); "reservoir" (`audio` IS a
         uint8 raster batch (B, C, T) on the device) -- the same rotation, launches and layout hint as a full step,
         so that per-stage timings go through the code the headline goes through.
+        `tail`: the caller has (almost) nothing to submit behind this step -- one of the last batches of a finite list
+        (`run()` sets it for the last `TAIL_STEPS` batches).  The step then takes the low-latency layouts: the front end
+        with one chain per lane (twice the waves, each half as long), the reservoir launch as a lone launch would be laid
+        out.  At the end of a burst the last front end otherwise runs alone on a quarter of the chip for ~2 ms while the
+        rest drains (profiles/r04_tail_steps.txt); inside a long run the normal layouts use fewer CU-cycles.
         Back-pressure: when `max_ahead` earlier steps have not finished, submit() first waits for the oldest."""
-        res, st = self._submit(audio, stats_out, after, out, stage)
+        res, st = self._submit(audio, stats_out, after, out, stage, tail)
         if st is not None and self.n_streams > 1:
             ev = torch.cuda.Event()
             ev.record(st)
             self._in_flight.append(ev)
         return res, st
 
-    def _submit(self, audio, stats_out=None, after=None, out=None, stage: str = "full"):
+    def _submit(self, audio, stats_out=None, after=None, out=None, stage: str = "full", tail: bool = False):
         """submit() without the in-flight bookkeeping."""
         if stage not in STAGES:
             raise ValueError(f"stage must be one of {STAGES}, got {stage!r}")
@@ -155,7 +166,7 @@ class HotPath:
                 cur.wait_event(after)
             with torch.cuda.device(self.device):
                 x = audio if stage == "reservoir" else self._to_device(audio, slot)
-                return self._one(x, stats_out, out, stage), cur
+                return self._one(x, stats_out, out, stage, tail), cur
         if self.n_fe_streams and stage != "reservoir":
             # two stages: front end on its own stream, the reservoir launch behind an event on another
             fslot = (self._step - 1) % self.n_fe_streams
@@ -171,7 +182,7 @@ class HotPath:
                     # route, which allocates its raster on the front-end stream): only the fused launch writes
                     # into the pipeline's rings, everything else goes through record_stream below
                     fuses = bool(getattr(self.fe, "will_fuse", lambda: False)())
-                    idle = self.wide_when_idle and len(self._fe_done) < self._wide_below and fuses
+                    idle = fuses and ((self.wide_when_idle and len(self._fe_done) < self._wide_below) or tail)
                     x = self._to_device(audio, ("fe", fslot))
                     pooled = self.pool and stage == "full" and fuses
                     if pooled:
@@ -201,7 +212,7 @@ class HotPath:
                     rasters.record_stream(st)      # allocated on the front-end stream, read on the reservoir stream
                 with torch.cuda.stream(st):
                     st.wait_event(done)
-                    feats = self._one(rasters, stats_out, out, "reservoir")
+                    feats = self._one(rasters, stats_out, out, "reservoir", tail)
                     if pooled:
                         free = torch.cuda.Event()
                         free.record(st)
@@ -213,7 +224,7 @@ class HotPath:
             elif on_device:
                 st.wait_stream(cur)
             x = audio if stage == "reservoir" else self._to_device(audio, slot)
-            return self._one(x, stats_out, out, stage), st
+            return self._one(x, stats_out, out, stage, tail), st
 
     def _to_device(self, audio, slot):
         if isinstance(audio, np.ndarray):
@@ -282,7 +293,8 @@ class HotPath:
         """Feature rows of every batch, in order, as one (n_clips, n_feat) device tensor.  `audio_batches`
         is an iterable of (B_i, n_samples) arrays/tensors (host or device)."""
         self.fork_from_current()
-        parts = [self.submit(a)[0] for a in audio_batches]
+        batches = list(audio_batches)
+        parts = [self.submit(a, tail=i >= len(batches) - TAIL_STEPS)[0] for i, a in enumerate(batches)]
         self.synchronize()
         if not parts:
             n_keys = len(self.feature_keys) if self.feature_keys is not None else 8
