@@ -210,6 +210,13 @@ int lsm_reservoir_plan(const lsm_reservoir *h, int n_clips, int n_steps, int wav
 int lsm_reservoir_row_request_bytes(const lsm_reservoir *h, int n_clips, int n_steps, int waves_per_clip,
                                     double *mean_bytes_out);
 
+/* How the planned kernel forms the input drive (introspection for tests): dense rows 0 = input-map entries streamed
+ * from global memory + LDS atomics, 1 = entries in registers + LDS atomics, 2 = per-neuron channel masks, four
+ * popcounts, 3 = channel masks at coloured bit positions, one popcount (C <= 128 and an assignment exists in which
+ * the channels feeding one neuron differ mod 32); ring rows 10 = packed entries streamed, 11 = packed entries in
+ * registers; sparse kernel 20. */
+int lsm_reservoir_input_mode(const lsm_reservoir *h, int n_clips, int n_steps, int waves_per_clip);
+
 /* Diagnostic builds (-DLSM_STAMP=1) only: per-phase s_memtime sums of the reservoir kernel
  * (out8: 8 counters, HOST memory); all zeros in the shipped build. */
 int lsm_debug_lif_stamps(unsigned long long *out8, int reset);

@@ -49,6 +49,7 @@ _SIGS = {
     "lsm_reservoir_plan": (c_int, [c_void, c_int, c_int, c_int, C.POINTER(c_int), C.POINTER(c_int),
                                    C.POINTER(c_int), C.POINTER(c_int), C.POINTER(C.c_long)]),
     "lsm_reservoir_row_request_bytes": (c_int, [c_void, c_int, c_int, c_int, C.POINTER(C.c_double)]),
+    "lsm_reservoir_input_mode": (c_int, [c_void, c_int, c_int, c_int]),
     "lsm_debug_lif_stamps": (c_int, [c_void, c_int]),
 }
 

@@ -58,6 +58,9 @@ namespace lsm_lif {
 #define LSM_RING_MARK(k)
 #endif
 
+#ifndef LSM_RING_DRIVE_ALL_LANES
+#define LSM_RING_DRIVE_ALL_LANES 0
+#endif
 #ifndef LSM_RING_ABLATE
 #define LSM_RING_ABLATE 0   // diagnostic builds only (1, 2, 8, 16, 32 give WRONG results): 1 = no window loads, 2 = no
 #endif                      // accumulator read-modify-write, 8 = no list loads, 16 = no input drive, 32 = no feature updates;
@@ -248,11 +251,20 @@ void lif_ring_kernel(const RingArgs a)
         uint32_t rw[EPL];
 #pragma unroll
         for (int u = 0; u < EPL; ++u) rw[u] = row[x[u] >> 21];
+        // Only the lanes whose channel is active add (about a quarter of them on speech-like rasters): what the drive
+        // costs is the LDS pipe's time for the atomics -- 8 per lane and step with all 64 lanes adding took 1.34 of
+        // cfg4's 6.17 ms (same-box build that issues the drive twice) --, and that time goes with the lanes that take
+        // part and the bank conflicts among them.
 #pragma unroll
         for (int u = 0; u < EPL; ++u) {
             const uint32_t bit = (rw[u] >> ((x[u] >> 16) & 31u)) & 1u;
-            const uint32_t inc = (bit << ((x[u] >> 11) & 16u)) & keep;
-            atomicAdd(reinterpret_cast<uint32_t *>(reinterpret_cast<unsigned char *>(cnt) + (x[u] & 0x7FFFu)), inc);
+            const uint32_t inc = bit << ((x[u] >> 11) & 16u);
+#if LSM_RING_DRIVE_ALL_LANES                       // diagnostic builds: every lane adds (zeros included)
+            atomicAdd(reinterpret_cast<uint32_t *>(reinterpret_cast<unsigned char *>(cnt) + (x[u] & 0x7FFFu)), inc & keep);
+#else
+            if (bit & keep)
+                atomicAdd(reinterpret_cast<uint32_t *>(reinterpret_cast<unsigned char *>(cnt) + (x[u] & 0x7FFFu)), inc);
+#endif
         }
     };
     auto input_drive = [&](int ts, uint32_t keep = 0xFFFFFFFFu) {

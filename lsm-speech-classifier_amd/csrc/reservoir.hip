@@ -553,6 +553,19 @@ int lsm_reservoir_destroy(lsm_reservoir *h) { return free_reservoir(h); }
 
 static bool lif_inreg(const Variant &v) { return v.einw <= IN_REG_SLOTS * 64; }
 
+static bool ring_inreg(const RingVariant &rv)
+{
+    // the wave's input map stays in registers when it is one block (8 registers) AND the layout has few neurons per
+    // lane: with three or four quads per wave the extra registers would cost a wave per SIMD
+    bool inreg = rv.einw <= lsm_lif::RING_ENT_BLOCK * lsm_lif::RING_ENT_REG_BLOCKS && rv.ql <= 2 && rv.strided;
+#if LSM_EXPERIMENT_HOOKS
+    static const bool no_inreg = [] { const char *e = getenv("LSM_RING_NO_INREG"); return e && atoi(e) != 0; }();
+    if (no_inreg) inreg = false;
+#endif
+    return inreg;
+}
+
+
 static size_t lif_lds_core(const lsm_reservoir *h, const Variant &v, int T)
 {
     const size_t npad = (size_t)v.sl * 64 * v.wpc;
@@ -811,13 +824,7 @@ static int reservoir_run(const lsm_reservoir *h, const uint8_t *spikes_u8, int n
     }
     if (plan.kernel == 3) {
         const RingVariant *rv = plan.rv;
-        // the wave's input map stays in registers when it is one block (8 registers) AND the layout has few neurons per
-        // lane: with three or four quads per wave the extra registers would cost a wave per SIMD
-        bool inreg = rv->einw <= lsm_lif::RING_ENT_BLOCK * lsm_lif::RING_ENT_REG_BLOCKS && rv->ql <= 2 && rv->strided;
-#if LSM_EXPERIMENT_HOOKS
-        static const bool no_inreg = [] { const char *e = getenv("LSM_RING_NO_INREG"); return e && atoi(e) != 0; }();
-        if (no_inreg) inreg = false;
-#endif
+        const bool inreg = ring_inreg(*rv);
         lsm_lif::ring_fn_t rfn = rv->ql == 1   ? lsm_lif::pick_ring_1(rv->wpc, inreg, rv->strided)
                                  : rv->ql == 2 ? lsm_lif::pick_ring_2(rv->wpc, inreg, rv->strided)
                                  : rv->ql == 3 ? lsm_lif::pick_ring_3(rv->wpc, inreg, rv->strided)
@@ -948,6 +955,17 @@ int lsm_reservoir_plan(const lsm_reservoir *h, int n_clips, int n_steps, int wav
     if (table_bytes_out)
         *table_bytes_out = p.kernel == 2 ? (long)((size_t)h->N * h->ld * 4) : (long)(h->nnz * 8 + ((size_t)h->N + 1) * 4);
     return LSM_OK;
+}
+
+extern "C" __attribute__((visibility("default")))
+int lsm_reservoir_input_mode(const lsm_reservoir *h, int n_clips, int n_steps, int waves_per_clip)
+{
+    if (h == nullptr) return LSM_ERR_ARG;
+    RunPlan p;
+    if (make_plan(h, n_clips, n_steps, waves_per_clip, &p) != LSM_OK) return LSM_ERR_UNSUPPORTED;
+    if (p.kernel == 3) return ring_inreg(*p.rv) ? 11 : 10;
+    if (p.kernel == 1) return 20;
+    return p.v->inmask ? (p.v->incol ? 3 : 2) : (lif_inreg(*p.v) ? 1 : 0);
 }
 
 extern "C" __attribute__((visibility("default")))

@@ -32,7 +32,7 @@ DEFAULT_HW_QUEUES = 12
 RASTER_DEPTH = 4                     # raster buffers per front-end stream (two-stage topology)
 # the last batches of a finite list take the low-latency layouts (HotPath.submit(tail=True)); measured at cfg2,
 # 20-step bursts (profiles/r04_tail_steps.txt)
-TAIL_STEPS = int(os.environ.get("LSM_TAIL_STEPS", "1"))
+TAIL_STEPS = int(os.environ.get("LSM_TAIL_STEPS", "2"))
 STAGES = ("full", "frontend", "reservoir")
 
 

@@ -194,7 +194,8 @@ class SNN:
                                                             C.byref(rb)), "lsm_reservoir_row_request_bytes")
         return {"kernel": {1: "sparse", 2: "dense", 3: "ring"}[k.value], "waves_per_clip": wpc.value,
                 "slots_per_lane": sl.value, "lds_bytes": lds.value, "table_bytes": tab.value,
-                "row_request_bytes": rb.value}
+                "row_request_bytes": rb.value,
+                "input_mode": int(self.lib.lsm_reservoir_input_mode(self._handle, n_clips, n_steps, waves_per_clip))}
 
     def layout(self, n_clips: int, n_steps: int, waves_per_clip: int = 0):
         wpc, sl, lds = C.c_int(), C.c_int(), C.c_int()

@@ -415,6 +415,44 @@ def test_oracle_on_a_reservoir_it_did_not_build(torch_cuda, oracle_c):
     np.testing.assert_array_equal(vt_np, vt_c)
 
 
+@pytest.mark.parametrize("hub_channels", [33, 32, 1])
+def test_input_maps_with_and_without_a_mask_colouring(torch_cuda, oracle_c, hub_channels):
+    """Round 4: the dense kernel counts a neuron's active inputs with ONE popcount when the library finds bit positions
+    for the channels such that the channels feeding one neuron differ mod 32 (INMODE 3, csrc/reservoir.hip
+    colour_input_channels).  A neuron fed by 33 channels admits no such assignment: the library must fall back to
+    the four-popcount form (INMODE 2) -- same results either way; 32 channels onto one neuron is the tightest map
+    that can be coloured; 1 is an ordinary map.  Reference semantics: SPEC.md 3 (input term w_in * count)."""
+    import copy
+    from lsm_speech_classifier_amd import snn, synth
+    n, k, c, t, fan = 1000, 60, 96, 150, 5
+    rasters = synth.bernoulli_raster(3, c, t, 0.3, seed=hub_channels)
+    res = copy.copy(_reservoir(n, k, 300, c, rasters))
+    rs = np.random.RandomState(hub_channels)
+    in_tgt = np.empty((c, fan), dtype=np.int32)
+    for ch in range(c):
+        others = rs.choice(np.arange(1, n), fan - 1, replace=False)
+        first = 0 if ch < hub_channels else int(rs.randint(1, n))     # the first `hub_channels` channels all feed neuron 0
+        while first in others:
+            first = int(rs.randint(1, n))
+        in_tgt[ch] = np.sort(np.append(others, first))
+    flat_c, flat_i = np.repeat(np.arange(c, dtype=np.int32), fan), in_tgt.reshape(-1)
+    o2 = np.lexsort((flat_c, flat_i))
+    in_ptr = np.zeros(n + 1, dtype=np.int32)
+    np.cumsum(np.bincount(flat_i, minlength=n), out=in_ptr[1:])
+    res.in_fanout, res.in_tgt, res.in_ptr, res.in_chan = fan, in_tgt, in_ptr, flat_c[o2].astype(np.int32)
+    assert np.bincount(flat_i, minlength=n)[0] >= hub_channels
+    net = snn.SNN(None, reservoir=res)
+    net.set_kernel("dense")
+    # one popcount (mode 3) when a colouring exists, four (mode 2) when 33 channels meet in one neuron
+    assert net.plan(3, t, 4)["input_mode"] == (2 if hub_channels > 32 else 3)
+    total = 0
+    for kernel in ("dense", "sparse"):
+        net.set_kernel(kernel)
+        for wpc in (0, 4, 8):
+            total += _check_against_oracle(net, rasters, oracle_c, wpc)
+    assert total > 500
+
+
 @pytest.mark.parametrize("n,k,c,t", [(1024, 120, 40, 120), (2048, 300, 96, 100), (4096, 300, 200, 80),
                                      (8192, 400, 256, 60), (6144, 500, 64, 60)])
 def test_ring_rows_at_quad_multiples(torch_cuda, oracle_c, n, k, c, t):
