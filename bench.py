@@ -279,7 +279,7 @@ def run_rank(args):
         torch.cuda.set_device(0)
     dev = torch.device("cuda", local_rank if use_dist else 0)
 
-    from lsm_speech_classifier_amd import frontend, reservoir, snn
+    from lsm_speech_classifier_amd import dist as lsm_dist, frontend, reservoir, snn
     from lsm_speech_classifier_amd.pipeline import HotPath, DEFAULT_STREAMS, TAIL_STEPS
     tail_steps = TAIL_STEPS if args.tail_steps is None else max(0, args.tail_steps)
     cfg = CONFIGS[args.config]
@@ -333,10 +333,8 @@ def run_rank(args):
     done_events = []                    # one event per step of the current phase (warm-up or timed), behind its last launch
 
     def gather_chunk(c0, c1):
-        """All-gather the rows of steps [c0, c1) of every rank.  `gathered` is laid out chunk by chunk, each chunk rank
-        by rank: chunk [c0, c1) occupies rows [world*c0*B, world*c1*B), rank r's steps inside it follow one another."""
-        dst = gathered[world * c0 * B: world * c1 * B]
-        dist.all_gather_into_tensor(dst, local_rows[c0:c1].reshape((c1 - c0) * B, n_feat))
+        """All-gather the rows of steps [c0, c1) of every rank (layout: lsm_speech_classifier_amd.dist.gather_step_chunk)."""
+        lsm_dist.gather_step_chunk(gathered, local_rows, c0, c1)
 
     def gather_behind(c0, c1):
         """The chunk's all-gather on the exchange stream, ordered behind the chunk's steps (GPU-side waits only).
@@ -480,14 +478,10 @@ def run_rank(args):
         # the gathered block holds every rank's rows, chunk by chunk: put them back into (rank, step, clip) order --
         # this rank's rows must come back unchanged, and the digest of the whole block is the same number whatever the
         # exchange mode (tests/test_gpu_hotpath.py compares 'once' and 'chunked')
-        bounds = [(c0, min(c0 + chunk, args.steps)) for c0 in range(0, args.steps, chunk)]
-        by_rank = [torch.cat([gathered[world * c0 * B + r * (c1 - c0) * B: world * c0 * B + (r + 1) * (c1 - c0) * B]
-                              for c0, c1 in bounds]) for r in range(world)]
+        by_rank = lsm_dist.rows_by_rank(gathered[: world * args.steps * B], world, args.steps, chunk, B)
         assert torch.equal(by_rank[rank], local_rows[:args.steps].reshape(-1, n_feat)), "all-gather returned other rows"
-        canon = torch.cat(by_rank).view(torch.int32).to(torch.int64).reshape(-1)
-        weights = torch.arange(canon.numel(), device=dev, dtype=torch.int64) % 65521 + 1
-        exchange_digest = int((canon * weights).sum().item())            # wraps in int64: deterministic
-        del by_rank, canon, weights
+        exchange_digest = lsm_dist.rows_digest(by_rank)                  # wraps in int64: deterministic
+        del by_rank
 
     if rank == 0:
         ms_step = elapsed / args.steps * 1e3

@@ -103,6 +103,23 @@ int lsm_mel_power_f32(const float *audio, int n_clips, int n_samples, int n_fft,
                       const float *basis_dev, const int32_t *lo_dev, const int32_t *hi_dev,
                       int n_mels, float *power_out, void *stream);
 
+/* The whole mel front end of a batch in ONE launch: melspectrogram (as lsm_mel_power_f32) -> power_to_db(ref=max) ->
+ * min-max normalise -> resize to time_bins columns -> hysteresis encoder -> row repeat (create_dataset.py:43-48 and
+ * :62-104 per clip).  Rasters equal those of lsm_mel_power_f32 + lsm_power_to_db_f32 + lsm_spec_to_spikes_f32 bit for
+ * bit (same code).  The workgroup that finishes a clip's last frame finishes the clip; nothing waits.
+ *   workspace        caller-owned, 256-byte aligned, >= lsm_mel_spikes_workspace(n_clips, n_mels, n_frames) bytes;
+ *                    its first n_clips*4 bytes (one counter per clip) must be ZERO on entry and are zero again when
+ *                    the launch has finished (allocate once with zeros, reuse for ever -- stream-ordered launches only)
+ *   raster           (n_clips, n_mels*redundancy, time_bins*n_thr) uint8
+ * LSM_ERR_UNSUPPORTED when the clip's bit-packed raster stage (n_mels rows) exceeds the kernel's 32 KB of LDS
+ * (more than ~600 filters at 4 thresholds x 100 bins): use the three split entry points. */
+long lsm_mel_spikes_workspace(int n_clips, int n_mels, int n_frames);
+int lsm_mel_spikes_f32(const float *audio, int n_clips, int n_samples, int n_fft, int hop, int n_frames,
+                       const double *window_dev, const double *twiddle_dev, const float *basis_dev,
+                       const int32_t *lo_dev, const int32_t *hi_dev, int n_mels, float amin, float top_db,
+                       int time_bins, const float *thr_on, const float *thr_off, int n_thr, int redundancy,
+                       uint8_t *raster, void *workspace, long workspace_bytes, void *stream);
+
 /* Replaces librosa.power_to_db(S, ref=np.max) (create_dataset.py:48) per clip, float32:
  * 10*log10(max(amin, S)) - 10*log10(max(amin, max S)), floored at -top_db. */
 int lsm_power_to_db_f32(const float *power, int n_clips, int n_per_clip, float amin, float top_db,

@@ -30,6 +30,10 @@ _SIGS = {
     "lsm_mel_power_f32": (c_int, [c_void, c_int, c_int, c_int, c_int, c_int, c_void, c_void, c_void,
                                   c_void, c_void, c_int, c_void, c_void]),
     "lsm_power_to_db_f32": (c_int, [c_void, c_int, c_int, c_float, c_float, c_void, c_void]),
+    "lsm_mel_spikes_workspace": (C.c_long, [c_int, c_int, c_int]),
+    "lsm_mel_spikes_f32": (c_int, [c_void, c_int, c_int, c_int, c_int, c_int, c_void, c_void, c_void, c_void, c_void,
+                                   c_int, c_float, c_float, c_int, c_void, c_void, c_int, c_int, c_void, c_void, C.c_long,
+                                   c_void]),
     "lsm_encode_hysteresis_f64": (c_int, [c_void, c_int, c_int, c_void, c_void, c_int, c_void, c_void]),
     "lsm_encode_hysteresis_f32": (c_int, [c_void, c_int, c_int, c_void, c_void, c_int, c_void, c_void]),
     "lsm_raster_pack_bits": (c_int, [c_void, C.c_long, c_int, c_void, c_void]),

@@ -10,7 +10,7 @@ ROOT = os.path.dirname(PKG_DIR)
 SOURCES = ["lsm_api.hip", "frontend.hip", "mel.hip", "reservoir.hip", "lif_variant_00.hip", "lif_variant_01.hip",
            "lif_variant_10.hip", "lif_variant_11.hip", "lif_dense_0.hip", "lif_dense_1.hip", "lif_dense_2.hip", "lif_dense_3.hip",
            "lif_ring_1.hip", "lif_ring_2.hip", "lif_ring_3.hip", "lif_ring_4.hip"]
-HEADERS = ["lsm_common.h", "lif_kernel.h", "lif_dense.h", "lif_ring.h"]
+HEADERS = ["lsm_common.h", "lif_kernel.h", "lif_dense.h", "lif_ring.h", "spikes_body.h"]
 LIB_NAME = "liblsm_hip.so"
 # -ffp-contract=off: the kernels must round every float operation exactly like the CPU oracle.
 CFLAGS = ["--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-fPIC", "-fvisibility=hidden",

@@ -8,6 +8,7 @@
 // One workgroup = one frame: real-input FFT as 1024 complex points, five radix-4 passes in LDS (float64),
 // |.|^2 in float32, then the triangular mel filters (four lanes per filter).
 #include "lsm_common.h"
+#include "spikes_body.h"
 
 namespace {
 
@@ -30,14 +31,25 @@ __device__ __forceinline__ double2 cmul(double2 a, double2 b)
 // z[n] = x[2n] + i x[2n+1], transformed by five radix-4 Stockham passes (one butterfly per thread and
 // pass, ping-pong between two LDS buffers, natural order in and out), and unpacked to the 1025 bins of
 // the real transform: X[k] = E[k] - i W^k O[k], E/O = (Z[k] +- conj Z[N2-k]) / 2.  All in float64.
-__global__ __launch_bounds__(256) void mel_power_kernel(
-    const float *__restrict__ audio, int n_samples, int hop, int n_frames,
-    const double *__restrict__ window, const double2 *__restrict__ twiddle,   // W_2048^k, k < 1024
-    const float *__restrict__ basis, const int *__restrict__ lo, const int *__restrict__ hi,
-    int n_mels, float *__restrict__ power_out)
+struct MelArgs {
+    const float *audio;
+    int n_samples, hop, n_frames, n_mels;
+    const double *window;
+    const double2 *twiddle;     // W_2048^k, k < 1024
+    const float *basis;
+    const int *lo, *hi;
+    float *power_out;
+};
+
+__device__ __forceinline__ void mel_power_body(const MelArgs &a, double2 (*buf)[N2], float *pw)
 {
-    __shared__ double2 buf[2][N2];              // 2 x 16 KB
-    __shared__ float pw[NBINS + 3];
+    const float *__restrict__ audio = a.audio;
+    const int n_samples = a.n_samples, hop = a.hop, n_frames = a.n_frames, n_mels = a.n_mels;
+    const double *__restrict__ window = a.window;
+    const double2 *__restrict__ twiddle = a.twiddle;
+    const float *__restrict__ basis = a.basis;
+    const int *__restrict__ lo = a.lo, *__restrict__ hi = a.hi;
+    float *__restrict__ power_out = a.power_out;
     const int t = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
     const float *clip = audio + (size_t)b * n_samples;
     const int start = t * hop - NFFT / 2;       // centred frame, zero padding outside the clip
@@ -100,14 +112,17 @@ __global__ __launch_bounds__(256) void mel_power_kernel(
     }
 }
 
-// librosa.power_to_db(S, ref=np.max): per clip, float32.
-__global__ __launch_bounds__(256) void power_to_db_kernel(const float *__restrict__ power, int n,
-                                                          float amin, float top_db,
-                                                          float *__restrict__ db_out)
+__global__ __launch_bounds__(256) void mel_power_kernel(const MelArgs a)
 {
-    __shared__ float red[4];
-    const float *p = power + (size_t)blockIdx.x * n;
-    float *o = db_out + (size_t)blockIdx.x * n;
+    __shared__ double2 buf[2][N2];              // 2 x 16 KB
+    __shared__ float pw[NBINS + 3];
+    mel_power_body(a, buf, pw);
+}
+
+// librosa.power_to_db(S, ref=np.max): per clip, float32; one 256-thread workgroup, `red`: 4 floats of LDS.
+__device__ __forceinline__ void power_to_db_body(const float *__restrict__ p, float *__restrict__ o, int n, float amin,
+                                                 float top_db, float *red)
+{
     float mx = -INFINITY;
     for (int i = threadIdx.x; i < n; i += 256) mx = fmaxf(mx, p[i]);
     for (int off = 32; off > 0; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off));
@@ -120,6 +135,54 @@ __global__ __launch_bounds__(256) void power_to_db_kernel(const float *__restric
         const float v = 10.0f * log10f(fmaxf(amin, p[i])) - refdb;
         o[i] = fmaxf(v, 0.0f - top_db);
     }
+}
+
+__global__ __launch_bounds__(256) void power_to_db_kernel(const float *__restrict__ power, int n,
+                                                          float amin, float top_db,
+                                                          float *__restrict__ db_out)
+{
+    __shared__ float red[4];
+    power_to_db_body(power + (size_t)blockIdx.x * n, db_out + (size_t)blockIdx.x * n, n, amin, top_db, red);
+}
+
+// The whole mel front end of a batch in ONE launch (create_dataset.py:43-48 + :62-104 per clip): grid = (frames, clips)
+// as in mel_power_kernel; every workgroup transforms its frame and projects it onto the mel filters, then counts itself
+// in on its clip.  The workgroup that arrives LAST for a clip -- all of the clip's power values are in memory then --
+// finishes the clip: power_to_db (the clip's maximum is the reference), min-max normalise, resize, hysteresis latches,
+// raster (lsm_fe::spec_to_spikes_body, the code of the split path).  No workgroup ever waits for another one: the
+// count is one atomic add whose returned value says who is last (the pattern MI355X_MICROARCH.md tabulates for a
+// consumer "told by the value its add returned"; the adder's stores are made visible by the fence before the add,
+// the finisher's loads are ordered by the fence after it).  The counters come in zero and leave zero.
+struct MelSpikeArgs {
+    MelArgs mel;                        // power_out = the power workspace (n_clips, n_mels, n_frames)
+    lsm_fe::SpikeArgs<float> sp;        // db = the dB workspace, same shape: written and read by the finishing workgroup
+    unsigned int *counters;             // (n_clips) zero
+    float amin, top_db;
+};
+
+__global__ __launch_bounds__(256) void mel_spikes_kernel(const MelSpikeArgs a)
+{
+    __shared__ double2 buf[2][N2];              // 2 x 16 KB; the finishing workgroup reuses it as the raster stage
+    __shared__ float pw[NBINS + 3];
+    __shared__ int last;
+    mel_power_body(a.mel, buf, pw);
+    const int b = blockIdx.y, tid = threadIdx.x;
+    __threadfence();                            // my power values are visible device-wide before my count is
+    __syncthreads();
+    if (tid == 0) {
+        const unsigned int prev = atomicAdd(a.counters + b, 1u);
+        last = prev == (unsigned int)a.mel.n_frames - 1u;
+        if (last) a.counters[b] = 0u;           // every workgroup of the clip has counted: reset for the next launch
+    }
+    __syncthreads();
+    if (!last) return;
+    __threadfence();                            // the other workgroups' values, not whatever this CU may have cached
+    const int n = a.mel.n_mels * a.mel.n_frames;
+    float *db = const_cast<float *>(a.sp.db) + (size_t)b * n;
+    power_to_db_body(a.mel.power_out + (size_t)b * n, db, n, a.amin, a.top_db, pw);
+    __threadfence();                            // dB values written by other threads of this workgroup
+    __syncthreads();
+    lsm_fe::spec_to_spikes_body<float>(a.sp, b, reinterpret_cast<unsigned char *>(buf));
 }
 
 }  // namespace
@@ -137,10 +200,65 @@ LSM_API int lsm_mel_power_f32(const float *audio, int n_clips, int n_samples, in
     if (n_clips == 0) return LSM_OK;
     LSM_REQUIRE(audio && window_dev && twiddle_dev && basis_dev && lo_dev && hi_dev && power_out,
                 "mel: null buffer");
-    hipLaunchKernelGGL(mel_power_kernel, dim3(n_frames, n_clips), dim3(256), 0, (hipStream_t)stream,
-                       audio, n_samples, hop, n_frames, window_dev,
-                       reinterpret_cast<const double2 *>(twiddle_dev), basis_dev, lo_dev, hi_dev,
-                       n_mels, power_out);
+    MelArgs a;
+    a.audio = audio; a.n_samples = n_samples; a.hop = hop; a.n_frames = n_frames; a.n_mels = n_mels;
+    a.window = window_dev; a.twiddle = reinterpret_cast<const double2 *>(twiddle_dev); a.basis = basis_dev;
+    a.lo = lo_dev; a.hi = hi_dev; a.power_out = power_out;
+    hipLaunchKernelGGL(mel_power_kernel, dim3(n_frames, n_clips), dim3(256), 0, (hipStream_t)stream, a);
+    LSM_CHECK_HIP(hipGetLastError());
+    return LSM_OK;
+}
+
+LSM_API long lsm_mel_spikes_workspace(int n_clips, int n_mels, int n_frames)
+{
+    if (n_clips < 0 || n_mels < 1 || n_frames < 1) return 0;
+    // power + dB spectrograms (float32 each) + one counter per clip, the counters first (they must start zeroed)
+    return (long)(((size_t)n_clips * 4 + 255) / 256 * 256) + 2L * n_clips * n_mels * n_frames * (long)sizeof(float);
+}
+
+LSM_API int lsm_mel_spikes_f32(const float *audio, int n_clips, int n_samples, int n_fft, int hop, int n_frames,
+                               const double *window_dev, const double *twiddle_dev, const float *basis_dev,
+                               const int32_t *lo_dev, const int32_t *hi_dev, int n_mels, float amin, float top_db,
+                               int time_bins, const float *thr_on, const float *thr_off, int n_thr, int redundancy,
+                               uint8_t *raster, void *workspace, long workspace_bytes, void *stream)
+{
+    LSM_REQUIRE(n_clips >= 0 && n_samples >= 1 && hop >= 1 && n_frames >= 2 && n_mels >= 1 && time_bins >= 2, "bad shape");
+    LSM_REQUIRE(n_fft == NFFT, "n_fft must be %d (librosa's default), got %d", NFFT, n_fft);
+    LSM_REQUIRE(n_clips <= 65535, "at most 65535 clips per call (grid.y)");
+    LSM_REQUIRE(n_thr >= 1 && n_thr <= lsm_fe::MAX_THR, "n_thr=%d outside [1, %d]", n_thr, lsm_fe::MAX_THR);
+    LSM_REQUIRE(redundancy >= 1, "redundancy must be >= 1");
+    LSM_REQUIRE(thr_on && thr_off, "null threshold table");
+    if (n_clips == 0) return LSM_OK;
+    LSM_REQUIRE(audio && window_dev && twiddle_dev && basis_dev && lo_dev && hi_dev && raster && workspace,
+                "mel_spikes: null buffer");
+    LSM_REQUIRE(workspace_bytes >= lsm_mel_spikes_workspace(n_clips, n_mels, n_frames),
+                "workspace of %ld bytes, need %ld (lsm_mel_spikes_workspace)", workspace_bytes,
+                lsm_mel_spikes_workspace(n_clips, n_mels, n_frames));
+    LSM_REQUIRE(((uintptr_t)workspace & 255u) == 0, "workspace must be 256-byte aligned");
+    const int row_bytes = time_bins * n_thr;
+    LSM_REQUIRE((row_bytes & 3) != 0 || ((uintptr_t)raster & 3u) == 0,
+                "the raster must be 4-byte aligned when a row is a multiple of 4 bytes");
+    // the finishing workgroup stages the clip's raster bit-packed in the FFT's two LDS buffers (32 KB)
+    const size_t stage = 64 + (size_t)n_mels * (((size_t)row_bytes + 31) / 32) * 4;
+    if (stage > sizeof(double2) * 2 * N2) {
+        lsm_set_error("mel_spikes: a raster stage of %zu bytes exceeds the kernel's 32 KB; use the split entry points", stage);
+        return LSM_ERR_UNSUPPORTED;
+    }
+    unsigned char *ws = static_cast<unsigned char *>(workspace);
+    const size_t cbytes = ((size_t)n_clips * 4 + 255) / 256 * 256;
+    float *power = reinterpret_cast<float *>(ws + cbytes);
+    float *db = power + (size_t)n_clips * n_mels * n_frames;
+    MelSpikeArgs a;
+    a.mel.audio = audio; a.mel.n_samples = n_samples; a.mel.hop = hop; a.mel.n_frames = n_frames; a.mel.n_mels = n_mels;
+    a.mel.window = window_dev; a.mel.twiddle = reinterpret_cast<const double2 *>(twiddle_dev); a.mel.basis = basis_dev;
+    a.mel.lo = lo_dev; a.mel.hi = hi_dev; a.mel.power_out = power;
+    a.sp.db = db; a.sp.n_clips = n_clips; a.sp.n_filters = n_mels; a.sp.ncols = n_frames; a.sp.time_bins = time_bins;
+    a.sp.apply_floor = 0;                       // the reference floors the gammatone branch only (create_dataset.py:60)
+    a.sp.n_thr = n_thr; a.sp.redundancy = redundancy; a.sp.raster = raster; a.sp.norm_out = nullptr;
+    for (int q = 0; q < lsm_fe::MAX_THR; ++q) { a.sp.on[q] = q < n_thr ? thr_on[q] : 0.0f; a.sp.off[q] = q < n_thr ? thr_off[q] : 0.0f; }
+    a.counters = reinterpret_cast<unsigned int *>(ws);
+    a.amin = amin; a.top_db = top_db;
+    hipLaunchKernelGGL(mel_spikes_kernel, dim3(n_frames, n_clips), dim3(256), 0, (hipStream_t)stream, a);
     LSM_CHECK_HIP(hipGetLastError());
     return LSM_OK;
 }

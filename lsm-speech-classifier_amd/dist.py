@@ -125,3 +125,44 @@ def broadcast_float(value: float, src: int = 0, device=None) -> float:
     t = torch.tensor([value], dtype=torch.float64, device=device)
     dist.broadcast(t, src)
     return float(t.item())
+
+
+# ---- the rows of a run of steps, exchanged in chunks (bench.py --exchange chunked) ------------------------------------
+# Every rank keeps (n_steps, B, F) rows; the rows of steps [c0, c1) travel in one all-gather as soon as those steps have
+# finished, into a block laid out chunk by chunk, each chunk rank by rank.  One place for that layout: the bench writes
+# with `gather_step_chunk` and reads with `rows_by_rank`; tests/test_dist_gloo.py runs both over gloo on the CPU.
+
+def chunk_bounds(n_steps: int, chunk: int):
+    """[c0, c1) of every chunk of `chunk` steps (the last one may be short)."""
+    chunk = max(1, int(chunk))
+    return [(c0, min(c0 + chunk, n_steps)) for c0 in range(0, n_steps, chunk)]
+
+
+def gather_step_chunk(gathered: torch.Tensor, local_rows: torch.Tensor, c0: int, c1: int) -> None:
+    """All-gather the rows of steps [c0, c1) of every rank.  `local_rows` is (n_steps, B, F) on this rank, `gathered`
+    (world * n_steps * B, F): the chunk occupies rows [world*c0*B, world*c1*B), rank r's steps inside it follow one
+    another.  Runs on the current stream (the caller orders it behind the chunk's steps)."""
+    world = dist.get_world_size() if dist.is_initialized() else 1
+    B, F = local_rows.shape[1], local_rows.shape[2]
+    src = local_rows[c0:c1].reshape((c1 - c0) * B, F)
+    dst = gathered[world * c0 * B: world * c1 * B]
+    if world == 1:
+        dst.copy_(src)
+    else:
+        dist.all_gather_into_tensor(dst, src)
+
+
+def rows_by_rank(gathered: torch.Tensor, world: int, n_steps: int, chunk: int, rows_per_step: int):
+    """The gathered block back in (rank, step, clip) order: a list of `world` tensors (n_steps * rows_per_step, F)."""
+    B = rows_per_step
+    return [torch.cat([gathered[world * c0 * B + r * (c1 - c0) * B: world * c0 * B + (r + 1) * (c1 - c0) * B]
+                       for c0, c1 in chunk_bounds(n_steps, chunk)]) for r in range(world)]
+
+
+def rows_digest(blocks) -> int:
+    """Order-sensitive 64-bit digest of row blocks (float32 bit patterns weighted by position, wrapping sum): equal for
+    two exchanges that delivered the same rows in the same (rank, step, clip) order."""
+    canon = torch.cat(list(blocks)).contiguous().view(torch.int32).to(torch.int64).reshape(-1)
+    weights = torch.arange(canon.numel(), device=canon.device, dtype=torch.int64) % 65521 + 1
+    return int((canon * weights).sum().item())
+

@@ -170,10 +170,22 @@ class SpikeFrontEnd:
 
     def will_fuse(self) -> bool:
         """Whether `encode()` takes the one-launch route by default.  ONE decision for `encode()` and for
-        `pipeline.HotPath`, which hands its own raster buffers to the fused launch only.
+        `pipeline.HotPath`, which hands its own raster buffers to the fused launch only.  Gammatone: up to 1024 filters
+        (`lsm_gammatone_spikes_f64`); mel: while the clip's raster stage fits the kernel's LDS (`lsm_mel_spikes_f32`, about
+        600 filters at the reference's 4 thresholds x 100 bins).
         LSM_FRONTEND_SPLIT=1: diagnostic switch for same-box A/B runs of the two routes (exp/r03_fused_sweep.sh)."""
-        return (self.filterbank == "gammatone" and self.n_filters <= 1024
-                and os.environ.get("LSM_FRONTEND_SPLIT") != "1")
+        if os.environ.get("LSM_FRONTEND_SPLIT") == "1":
+            return False
+        if self.filterbank == "mel":
+            return self._mel.fits_one_launch(self.time_bins, len(self.thresholds))
+        return self.n_filters <= 1024
+
+    def new_workspace(self, n_clips: int) -> torch.Tensor:
+        """Scratch of the one-launch route for batches of up to `n_clips` clips, to pass as `encode(workspace=...)`: one per
+        stream when launches may overlap (the mel scratch carries per-clip arrival counters and starts zeroed)."""
+        if self.filterbank == "mel":
+            return self._mel.new_workspace(n_clips)
+        return torch.empty((self.workspace_elems(n_clips),), dtype=torch.float64, device=self.device)
 
     def _audio(self, audio) -> torch.Tensor:
         if isinstance(audio, np.ndarray):
@@ -225,13 +237,14 @@ class SpikeFrontEnd:
 
     def encode(self, audio, fused: bool | None = None, low_latency: bool = False,
                raster_out: torch.Tensor | None = None, workspace: torch.Tensor | None = None) -> torch.Tensor:
-        """audio (B, n_samples) -> uint8 spike raster (B, C, n_steps) on the device.  The gammatone branch
-        is one launch (`lsm_gammatone_spikes_f64`); `fused=False` takes the two split entry points
-        (identical rasters), which is also what the mel branch and > 1024 filters use.  `low_latency`: the
+        """audio (B, n_samples) -> uint8 spike raster (B, C, n_steps) on the device.  One launch on both branches
+        (`lsm_gammatone_spikes_f64` / `lsm_mel_spikes_f32`); `fused=False` takes the split entry points (identical
+        rasters), which is also what filterbanks too wide for the one-launch kernels use (`will_fuse()`).  `low_latency`: the
         fused launch in its one-chain layout (twice the waves, each half as long) -- for a batch that meets an idle
         GPU; `pipeline.HotPath` asks for it when none of its front ends is in flight.  `raster_out` / `workspace`
-        (fused launch only): caller-owned uint8 (B, C, n_steps) output and float64 scratch of at least
-        `workspace_elems(B)` elements, so that a steady stream of batches makes no allocator call at all."""
+        (fused launch only): caller-owned uint8 (B, C, n_steps) output and scratch from `new_workspace(B)` (gammatone:
+        float64, at least `workspace_elems(B)` elements; mel: zero-initialised bytes), so that a steady stream of
+        batches makes no allocator call at all."""
         if fused is None:
             fused = self.will_fuse()
         if not fused:
@@ -243,10 +256,14 @@ class SpikeFrontEnd:
             db, _ = self.spectrogram_db(audio)
             raster, _ = self.spikes_from_db(db)
             return raster
-        if self.filterbank != "gammatone":
-            raise ValueError("the fused front end is the gammatone branch")
         audio = self._audio(audio)
         B = audio.shape[0]
+        if self.filterbank == "mel":
+            if not self._mel.fits_one_launch(self.time_bins, len(self.thresholds)):
+                raise ValueError(f"{self.n_filters} mel filters do not fit the one-launch front end; use fused=False")
+            on32, off32 = threshold_tables(self.thresholds, self.gap, np.float32)
+            with torch.cuda.device(self.device):
+                return self._mel.spikes(audio, on32, off32, self.time_bins, self.redundancy, raster_out, workspace)
         on, off = threshold_tables(self.thresholds, self.gap, np.float64)
         with torch.cuda.device(self.device):
             shape = (B, self.n_channels, self.n_steps)

@@ -68,6 +68,9 @@ class MelSpectrogram:
         to = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(self.device)
         self.window, self.twiddle = to(window), to(tw)
         self.basis, self.lo, self.hi = to(basis), to(lo), to(hi)
+        # scratch of the one-launch front end per (batch size, stream).  A workspace carries the clips' arrival counters,
+        # so two launches that may overlap (different streams) must not share one; pipeline.HotPath owns one per stream.
+        self._ws = {}
 
     def power(self, audio: torch.Tensor) -> torch.Tensor:
         B = audio.shape[0]
@@ -78,6 +81,47 @@ class MelSpectrogram:
             p(self.twiddle), p(self.basis), p(self.lo), p(self.hi), self.n_mels, p(out),
             torch.cuda.current_stream(self.device).cuda_stream), "lsm_mel_power_f32")
         return out
+
+    def workspace_bytes(self, n_clips: int) -> int:
+        return int(self.lib.lsm_mel_spikes_workspace(int(n_clips), self.n_mels, self.n_frames))
+
+    def new_workspace(self, n_clips: int) -> torch.Tensor:
+        """Zeroed scratch of the one-launch front end for batches of up to `n_clips` clips (the per-clip counters at its
+        start must be zero on entry; every launch leaves them zero, so one workspace serves a stream of batches)."""
+        return torch.zeros((max(self.workspace_bytes(n_clips), 256),), dtype=torch.uint8, device=self.device)
+
+    def fits_one_launch(self, time_bins: int, n_thr: int) -> bool:
+        """The finishing workgroup stages the clip's bit-packed raster in the FFT's 32 KB of LDS."""
+        return 64 + self.n_mels * ((time_bins * n_thr + 31) // 32) * 4 <= 32768
+
+    def spikes(self, audio: torch.Tensor, on: np.ndarray, off: np.ndarray, time_bins: int, redundancy: int,
+               raster_out: torch.Tensor | None = None, workspace: torch.Tensor | None = None) -> torch.Tensor:
+        """(B, n_samples) float32 -> uint8 raster (B, n_mels*redundancy, time_bins*len(on)) in ONE launch
+        (`lsm_mel_spikes_f32`): mel power -> dB -> normalise -> resize -> hysteresis encoder."""
+        B = audio.shape[0]
+        shape = (B, self.n_mels * redundancy, time_bins * len(on))
+        raster = raster_out if raster_out is not None else torch.empty(shape, dtype=torch.uint8, device=self.device)
+        if tuple(raster.shape) != shape or raster.dtype != torch.uint8 or not raster.is_contiguous():
+            raise ValueError(f"raster_out must be a contiguous uint8 {shape} tensor")
+        need = self.workspace_bytes(B)
+        stream = torch.cuda.current_stream(self.device).cuda_stream
+        if workspace is None:
+            ws = self._ws.get((B, stream))         # launches on ONE stream run in order: they may share a workspace
+            if ws is None:
+                ws = self._ws[(B, stream)] = self.new_workspace(B)
+        else:
+            ws = workspace
+            if ws.dtype != torch.uint8 or ws.numel() < need or ws.device != raster.device or ws.data_ptr() % 256:
+                raise ValueError(f"workspace must be a zero-initialised, 256-byte aligned uint8 tensor of >= {need} bytes")
+        p = lambda t: C.c_void_p(t.data_ptr())
+        h = lambda a: C.c_void_p(a.ctypes.data)
+        on = np.ascontiguousarray(on, dtype=np.float32)
+        off = np.ascontiguousarray(off, dtype=np.float32)
+        _lib.check(self.lib.lsm_mel_spikes_f32(
+            p(audio), B, self.n_samples, N_FFT, self.hop, self.n_frames, p(self.window), p(self.twiddle),
+            p(self.basis), p(self.lo), p(self.hi), self.n_mels, C.c_float(AMIN), C.c_float(TOP_DB), int(time_bins),
+            h(on), h(off), len(on), int(redundancy), p(raster), p(ws), int(ws.numel()), stream), "lsm_mel_spikes_f32")
+        return raster
 
     def power_db(self, audio: torch.Tensor) -> torch.Tensor:
         """(B, n_samples) float32 -> power_to_db(melspectrogram) float32 (B, n_mels, n_frames)."""

@@ -193,15 +193,16 @@ class HotPath:
                                 [torch.empty((x.shape[0], self.fe.n_channels, self.fe.n_steps), dtype=torch.uint8,
                                              device=self.device) for _ in range(RASTER_DEPTH)],
                                 [None] * RASTER_DEPTH, 0]
-                            self._ws[key] = torch.empty((self.fe.workspace_elems(x.shape[0]),), dtype=torch.float64,
-                                                        device=self.device)
+                            self._ws[key] = self.fe.new_workspace(x.shape[0])        # one per front-end stream
                         bi = ring[2]
                         ring[2] = (bi + 1) % RASTER_DEPTH
                         if ring[1][bi] is not None:
                             fst.wait_event(ring[1][bi])          # its last reader (a reservoir launch) has finished
-                        rasters = self.fe.encode(x, low_latency=idle, raster_out=ring[0][bi], workspace=self._ws[key])
+                        rasters = self.fe.encode(x, low_latency=idle and self.fe.filterbank == "gammatone",
+                                                 raster_out=ring[0][bi], workspace=self._ws[key])
                     else:
-                        rasters = self.fe.encode(x, low_latency=True) if idle else self.fe.encode(x)
+                        lowlat = idle and getattr(self.fe, "filterbank", "") == "gammatone"
+                        rasters = self.fe.encode(x, low_latency=True) if lowlat else self.fe.encode(x)
                         pooled = False
                     done = torch.cuda.Event()
                     done.record(fst)

@@ -48,7 +48,23 @@ def main():
     if gpu:
         block = block.cuda()
     var = lsm_dist.gather_varrows(block).cpu().numpy()
-    np.savez(os.path.join(out_dir, f"rank{rank}.npz"), feats=feats, lo=lo, hi=hi, w=w, var=var)
+    # the bench's exchange of a run of steps in chunks (tail chunk included) against one gather of everything
+    steps, B, F = 7, 3, 4
+    mine = (torch.arange(steps * B * F, dtype=torch.float32).reshape(steps, B, F) + 1000.0 * rank)
+    if gpu:
+        mine = mine.cuda()
+    digests = []
+    for chunk in (3, steps, 1):
+        gathered = torch.full((world * steps * B, F), -1.0, dtype=torch.float32, device=mine.device)
+        for c0, c1 in lsm_dist.chunk_bounds(steps, chunk):
+            lsm_dist.gather_step_chunk(gathered, mine, c0, c1)
+        blocks = lsm_dist.rows_by_rank(gathered, world, steps, chunk, B)
+        for r in range(world):
+            want = torch.arange(steps * B * F, dtype=torch.float32).reshape(steps * B, F) + 1000.0 * r
+            assert torch.equal(blocks[r].cpu(), want), (chunk, r)
+        digests.append(lsm_dist.rows_digest(blocks))
+    assert digests[0] == digests[1] == digests[2] != 0
+    np.savez(os.path.join(out_dir, f"rank{rank}.npz"), feats=feats, lo=lo, hi=hi, w=w, var=var, digest=digests[0])
     torch.distributed.barrier()
     torch.distributed.destroy_process_group()
 

@@ -47,3 +47,5 @@ def test_sharded_feature_gather_equals_single_process(tmp_path, world, n):
                                for r in range(world)])
         np.testing.assert_array_equal(d["var"], want)               # ragged blocks, rank order, every rank
     assert covered == list(range(n))
+    # bench.py's chunked exchange (dist.gather_step_chunk / rows_by_rank): asserted inside every rank; all ranks agree
+    assert len({int(np.load(tmp_path / f"rank{rank}.npz")["digest"]) for rank in range(world)}) == 1

@@ -70,3 +70,68 @@ def test_audio_to_spectrogram_mel_single_clip():
     out = frontend.audio_to_spectrogram(audio, 40, "mel")
     assert out.shape == (40, 100) and out.dtype == np.float32
     np.testing.assert_allclose(out, O.normalise_resize(O.mel_db(audio, 40)), rtol=0, atol=5e-5)
+
+
+@pytest.mark.parametrize("n_mels,redundancy,thr,gap", [(40, 1, THR, 0.1), (128, 1, THR, 0.1), (13, 2, [0.5, 0.9], 0.05),
+                                                       (200, 1, [0.3, 0.6, 0.65, 0.7, 0.8, 0.9, 0.95, 0.99], 0.02)])
+def test_one_launch_mel_front_end_equals_the_three_launch_route(n_mels, redundancy, thr, gap):
+    """Round 4: `lsm_mel_spikes_f32` -- mel power, power_to_db, normalise, resize, encoder in one launch,
+    the workgroup that finishes a clip's last frame finishing the clip -- gives the rasters of the split route
+    (`lsm_mel_power_f32` -> `lsm_power_to_db_f32` -> `lsm_spec_to_spikes_f32`) bit for bit: batches of 1..9 clips, a silent
+    clip, repeated launches on one workspace (the arrival counters are left zeroed), 1-8 thresholds, row repeat.
+    Reference: /root/reference/create_dataset.py:43-48, 62-104."""
+    import torch
+    from lsm_speech_classifier_amd import frontend
+    fe = frontend.SpikeFrontEnd(n_mels, "mel", redundancy=redundancy, thresholds=thr, gap=gap)
+    assert fe.will_fuse()
+    audio = _audio(9, seed=n_mels)
+    audio[3] = 0.0
+    dev = torch.from_numpy(audio).cuda()
+    split = fe.encode(dev, fused=False)
+    for rep in range(3):                                   # the same cached workspace every time
+        fused = fe.encode(dev)
+        assert fused.shape == (9, n_mels * redundancy, 100 * len(thr)) and torch.equal(fused, split), rep
+    assert split.any() and not split[3].any()
+    for n in (1, 2, 5):
+        assert torch.equal(fe.encode(dev[:n]), split[:n])
+    ws = fe.new_workspace(9)
+    out = torch.empty_like(split)
+    assert fe.encode(dev, raster_out=out, workspace=ws) is out and torch.equal(out, split)
+    torch.cuda.synchronize()
+    assert not ws[:9 * 4].any()                            # counters back at zero
+    with pytest.raises(ValueError):
+        fe.encode(dev, workspace=torch.zeros(16, dtype=torch.uint8, device="cuda"))
+
+
+def test_mel_filterbanks_too_wide_for_one_launch_take_the_split_route():
+    import torch
+    from lsm_speech_classifier_amd import frontend, synth
+    fe = frontend.SpikeFrontEnd(700, "mel")
+    assert not fe.will_fuse()
+    audio = synth.class_chirps([0, 4], seed=5)
+    r = fe.encode(audio)                                    # split route, silently
+    assert r.shape == (2, 700, 400) and r.any()
+    with pytest.raises(ValueError):
+        fe.encode(audio, fused=True)
+
+
+def test_hotpath_with_the_mel_front_end_equals_the_serial_path():
+    """cfg1's shape through the overlapped pipeline: front ends on streams of their own, each with its OWN workspace (two
+    launches sharing the arrival counters would finish each other's clips), rows equal to the serial path."""
+    import torch
+    from lsm_speech_classifier_amd import frontend, pipeline, reservoir as R, snn, synth
+    from oracle import ref_numpy as O
+    keys = ['spike_counts', 'spike_variances', 'mean_spike_times', 'mean_isi', 'isi_variances']
+    audio = synth.class_chirps(np.arange(6 * 50) % 4, seed=11)
+    fe = frontend.SpikeFrontEnd(40, "mel")
+    rasters = fe.encode(audio, fused=False)
+    p = R.SimulationParams(num_neurons=500, num_output_neurons=200, small_world_graph_k=100,
+                           mean_weight=O.w_critico(100, 2.0, 2, rasters.cpu().numpy()) * 0.6)
+    net = snn.SNN(None, reservoir=R.build_reservoir(p, 40))
+    serial, _, _ = net.run_batch(rasters, keys)
+    batches = [torch.from_numpy(audio[lo:lo + 50]).cuda() for lo in range(0, len(audio), 50)]
+    for streams, fes in ((1, None), (4, 0), (6, None)):
+        hp = pipeline.HotPath(fe, net, keys, streams=streams, fe_streams=fes)
+        for rep in range(3):
+            assert torch.equal(hp.run(batches), serial), (streams, fes, rep)
+    assert len({w.data_ptr() for w in hp._ws.values()}) == len(hp._ws) >= 2
