@@ -58,6 +58,9 @@ namespace lsm_lif {
 #define LSM_RING_MARK(k)
 #endif
 
+#ifndef LSM_RING_DRIVE_AT
+#define LSM_RING_DRIVE_AT 1     // 1 = behind the first row loads of the step (product), 0 = at the top of the step
+#endif
 #ifndef LSM_RING_DRIVE_ALL_LANES
 #define LSM_RING_DRIVE_ALL_LANES 0
 #endif
@@ -245,8 +248,8 @@ void lif_ring_kernel(const RingArgs a)
     // per lane, straight-line: the 8 row-word reads are in flight together, then the 8 atomics -- the first version
     // read, waited and added entry by entry behind per-entry guards, and a same-box build that issued the drive twice
     // put it at 1.49 of cfg4's 6.44 ms (profiles/r04_ring_input_drive.txt).  A wave's entries only ever touch the counts
-    // of its own neurons, which it cleared itself in the previous update: the drive needs no barrier and runs at the TOP
-    // of the step, so its LDS round trips overlap the spike-list set-up and the first row loads.
+    // of its own neurons, which it cleared itself in the previous update: the drive needs no barrier and can run anywhere
+    // between two updates of its wave.
     auto drive_block = [&](const uint32_t *row, const uint32_t (&x)[EPL], uint32_t keep) __attribute__((always_inline)) {
         uint32_t rw[EPL];
 #pragma unroll
@@ -295,14 +298,21 @@ void lif_ring_kernel(const RingArgs a)
         const uint16_t *list_prev = wlist + prv * NPAD;
         uint16_t *list_cur = wlist + cur * NPAD;
 
-        // ---- input drive first (independent of the rows; see input_drive) ----
-        if (!(LSM_RING_ABLATE & 16)) input_drive(t);
-        if (LSM_RING_ABLATE & 64) {
-            uint32_t zero = 0u;
-            asm volatile("" : "+s"(zero));          // opaque: the second pass is not folded away
-            input_drive(t, zero);
-        }
-        LSM_RING_MARK(4)               // input counts issued (the fetch of streamed input-map entries included)
+        // The input drive is independent of the rows (see input_drive): it is issued once per step behind the first
+        // row loads of the step, so that its LDS round trips run while those loads are in flight (LSM_RING_DRIVE_AT: 0 =
+        // at the top of the step instead, diagnostic builds).
+        bool drove = false;
+        auto drive_once = [&]() __attribute__((always_inline)) {
+            if (drove) return;
+            drove = true;
+            if (!(LSM_RING_ABLATE & 16)) input_drive(t);
+            if (LSM_RING_ABLATE & 64) {
+                uint32_t zero = 0u;
+                asm volatile("" : "+s"(zero));      // opaque: the second pass is not folded away
+                input_drive(t, zero);
+            }
+        };
+        if (LSM_RING_DRIVE_AT == 0) drive_once();
 
         // ---- spiking neurons of step t-1: prefix of the per-quad counts, lane l <- l-th neuron ----
         const uint32_t cv = wcnt[prv * 32 + (lane & 31)];
@@ -451,6 +461,8 @@ void lif_ring_kernel(const RingArgs a)
                 LSM_RING_LOADL(p, p)
             }
             LSM_RING_MARK(2)           // first P rows requested
+            drive_once();
+            LSM_RING_MARK(4)           // input counts issued (the fetch of streamed input-map entries included)
             LSM_RING_READ(0)
             for (int m = 0; m < n; m += P) {
 #pragma unroll
@@ -467,6 +479,7 @@ void lif_ring_kernel(const RingArgs a)
 #undef LSM_RING_READ
 #undef LSM_RING_APPLY
         }
+        drive_once();                  // a step without reservoir spikes: no rows to hide behind
         wave_lds_fence();
 
         // ---- neuron update, quad by quad: leak/integrate/threshold by select, then (only if a neuron of the
