@@ -59,8 +59,9 @@ namespace lsm_lif {
 #endif
 
 #ifndef LSM_RING_DRIVE_AT
-#define LSM_RING_DRIVE_AT 1     // 1 = behind the first row loads of the step (product), 0 = at the top of the step
-#endif
+#define LSM_RING_DRIVE_AT 0     // 0 = at the top of the step (product: 6.09 ms at cfg4), 1 = behind the first row loads of the step
+#endif                          // (6.13 ms and seven spilled registers: profiles/r04_ring_input_drive.txt)
+
 #ifndef LSM_RING_DRIVE_ALL_LANES
 #define LSM_RING_DRIVE_ALL_LANES 0
 #endif
@@ -298,9 +299,8 @@ void lif_ring_kernel(const RingArgs a)
         const uint16_t *list_prev = wlist + prv * NPAD;
         uint16_t *list_cur = wlist + cur * NPAD;
 
-        // The input drive is independent of the rows (see input_drive): it is issued once per step behind the first
-        // row loads of the step, so that its LDS round trips run while those loads are in flight (LSM_RING_DRIVE_AT: 0 =
-        // at the top of the step instead, diagnostic builds).
+        // The input drive is independent of the rows (see input_drive): it is issued once per step, at the top (behind
+        // the first row loads of the step -- LSM_RING_DRIVE_AT=1, diagnostic builds -- it measured 0.7 % slower).
         bool drove = false;
         auto drive_once = [&]() __attribute__((always_inline)) {
             if (drove) return;
@@ -313,6 +313,7 @@ void lif_ring_kernel(const RingArgs a)
             }
         };
         if (LSM_RING_DRIVE_AT == 0) drive_once();
+        LSM_RING_MARK(4)               // input counts issued (the fetch of streamed input-map entries included)
 
         // ---- spiking neurons of step t-1: prefix of the per-quad counts, lane l <- l-th neuron ----
         const uint32_t cv = wcnt[prv * 32 + (lane & 31)];
@@ -461,8 +462,7 @@ void lif_ring_kernel(const RingArgs a)
                 LSM_RING_LOADL(p, p)
             }
             LSM_RING_MARK(2)           // first P rows requested
-            drive_once();
-            LSM_RING_MARK(4)           // input counts issued (the fetch of streamed input-map entries included)
+            if (LSM_RING_DRIVE_AT == 1) drive_once();
             LSM_RING_READ(0)
             for (int m = 0; m < n; m += P) {
 #pragma unroll

@@ -9,6 +9,7 @@
 // |.|^2 in float32, then the triangular mel filters (four lanes per filter).
 #include "lsm_common.h"
 #include "spikes_body.h"
+#include <cstdlib>
 
 namespace {
 
@@ -41,7 +42,7 @@ struct MelArgs {
     float *power_out;
 };
 
-__device__ __forceinline__ void mel_power_body(const MelArgs &a, double2 (*buf)[N2], float *pw)
+__device__ __forceinline__ void mel_power_body(const MelArgs &a, double2 (*buf)[N2], float *pw, const int t)
 {
     const float *__restrict__ audio = a.audio;
     const int n_samples = a.n_samples, hop = a.hop, n_frames = a.n_frames, n_mels = a.n_mels;
@@ -50,7 +51,7 @@ __device__ __forceinline__ void mel_power_body(const MelArgs &a, double2 (*buf)[
     const float *__restrict__ basis = a.basis;
     const int *__restrict__ lo = a.lo, *__restrict__ hi = a.hi;
     float *__restrict__ power_out = a.power_out;
-    const int t = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+    const int b = blockIdx.y, tid = threadIdx.x;
     const float *clip = audio + (size_t)b * n_samples;
     const int start = t * hop - NFFT / 2;       // centred frame, zero padding outside the clip
 
@@ -116,7 +117,7 @@ __global__ __launch_bounds__(256) void mel_power_kernel(const MelArgs a)
 {
     __shared__ double2 buf[2][N2];              // 2 x 16 KB
     __shared__ float pw[NBINS + 3];
-    mel_power_body(a, buf, pw);
+    mel_power_body(a, buf, pw, (int)blockIdx.x);
 }
 
 // librosa.power_to_db(S, ref=np.max): per clip, float32; one 256-thread workgroup, `red`: 4 floats of LDS.
@@ -158,6 +159,7 @@ struct MelSpikeArgs {
     lsm_fe::SpikeArgs<float> sp;        // db = the dB workspace, same shape: written and read by the finishing workgroup
     unsigned int *counters;             // (n_clips) zero
     float amin, top_db;
+    int frames_per_wg;                  // a workgroup transforms this many consecutive frames: grid.x = ceil(n_frames / it)
 };
 
 __global__ __launch_bounds__(256) void mel_spikes_kernel(const MelSpikeArgs a)
@@ -165,22 +167,31 @@ __global__ __launch_bounds__(256) void mel_spikes_kernel(const MelSpikeArgs a)
     __shared__ double2 buf[2][N2];              // 2 x 16 KB; the finishing workgroup reuses it as the raster stage
     __shared__ float pw[NBINS + 3];
     __shared__ int last;
-    mel_power_body(a.mel, buf, pw);
     const int b = blockIdx.y, tid = threadIdx.x;
-    __threadfence();                            // my power values are visible device-wide before my count is
+    // A workgroup takes `frames_per_wg` consecutive frames, one after the other: the release fence below writes the
+    // XCD's dirty L2 lines back (the eight L2s are not coherent with each other), which costs about a microsecond, so
+    // it is paid once per group of frames, not once per frame (one frame per workgroup: 2.4 instead of 0.3 ms per
+    // 200 clips, profiles/r04_mel_one_launch_ab.txt).
+    const int t0 = (int)blockIdx.x * a.frames_per_wg;
+    const int t1 = min(t0 + a.frames_per_wg, a.mel.n_frames);
+    for (int t = t0; t < t1; ++t) {
+        if (t > t0) __syncthreads();            // the previous frame's LDS buffers are free again
+        mel_power_body(a.mel, buf, pw, t);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");      // my power values are visible device-wide before my count is
     __syncthreads();
     if (tid == 0) {
         const unsigned int prev = atomicAdd(a.counters + b, 1u);
-        last = prev == (unsigned int)a.mel.n_frames - 1u;
+        last = prev == gridDim.x - 1u;
         if (last) a.counters[b] = 0u;           // every workgroup of the clip has counted: reset for the next launch
     }
     __syncthreads();
     if (!last) return;
-    __threadfence();                            // the other workgroups' values, not whatever this CU may have cached
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");      // the other workgroups' values, not whatever this CU may have cached
     const int n = a.mel.n_mels * a.mel.n_frames;
     float *db = const_cast<float *>(a.sp.db) + (size_t)b * n;
     power_to_db_body(a.mel.power_out + (size_t)b * n, db, n, a.amin, a.top_db, pw);
-    __threadfence();                            // dB values written by other threads of this workgroup
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");  // dB values written by other threads of this workgroup
     __syncthreads();
     lsm_fe::spec_to_spikes_body<float>(a.sp, b, reinterpret_cast<unsigned char *>(buf));
 }
@@ -258,7 +269,16 @@ LSM_API int lsm_mel_spikes_f32(const float *audio, int n_clips, int n_samples, i
     for (int q = 0; q < lsm_fe::MAX_THR; ++q) { a.sp.on[q] = q < n_thr ? thr_on[q] : 0.0f; a.sp.off[q] = q < n_thr ? thr_off[q] : 0.0f; }
     a.counters = reinterpret_cast<unsigned int *>(ws);
     a.amin = amin; a.top_db = top_db;
-    hipLaunchKernelGGL(mel_spikes_kernel, dim3(n_frames, n_clips), dim3(256), 0, (hipStream_t)stream, a);
+    // frames per workgroup: few enough release fences, enough workgroups to fill the chip (>= ~8 per CU-slot when the
+    // batch is small; a workgroup holds 36 KB of LDS, four fit a CU)
+    int fpw = 16;
+#if LSM_EXPERIMENT_HOOKS
+    static const int fpw_env = [] { const char *e = getenv("LSM_MEL_FRAMES_PER_WG"); return e ? atoi(e) : 0; }();
+    if (fpw_env >= 1) fpw = fpw_env;
+#endif
+    fpw = fpw > n_frames ? n_frames : fpw;
+    a.frames_per_wg = fpw;
+    hipLaunchKernelGGL(mel_spikes_kernel, dim3((n_frames + fpw - 1) / fpw, n_clips), dim3(256), 0, (hipStream_t)stream, a);
     LSM_CHECK_HIP(hipGetLastError());
     return LSM_OK;
 }
