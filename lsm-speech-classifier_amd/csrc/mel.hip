@@ -269,9 +269,11 @@ LSM_API int lsm_mel_spikes_f32(const float *audio, int n_clips, int n_samples, i
     for (int q = 0; q < lsm_fe::MAX_THR; ++q) { a.sp.on[q] = q < n_thr ? thr_on[q] : 0.0f; a.sp.off[q] = q < n_thr ? thr_off[q] : 0.0f; }
     a.counters = reinterpret_cast<unsigned int *>(ws);
     a.amin = amin; a.top_db = top_db;
-    // frames per workgroup: few enough release fences, enough workgroups to fill the chip (>= ~8 per CU-slot when the
-    // batch is small; a workgroup holds 36 KB of LDS, four fit a CU)
-    int fpw = 16;
+    // Frames per workgroup (profiles/r04_mel_one_launch_ab.txt, 40 filters x 200 clips, ms per step front ends alone /
+    // on one stream): 1 frame 1.72 / 1.75, 4: 0.89 / 0.79, 8: 0.58 / 0.60, 16: 0.45 / 0.54, 32: 0.36 / 0.55, the whole clip
+    // (101) 0.30 / 0.90; the three split launches 0.28 / 0.33.  A batch that gives every other CU a clip takes the whole
+    // clip per workgroup (best throughput when launches overlap), smaller batches 32 frames (more workgroups).
+    int fpw = n_clips >= 128 ? n_frames : 32;
 #if LSM_EXPERIMENT_HOOKS
     static const int fpw_env = [] { const char *e = getenv("LSM_MEL_FRAMES_PER_WG"); return e ? atoi(e) : 0; }();
     if (fpw_env >= 1) fpw = fpw_env;

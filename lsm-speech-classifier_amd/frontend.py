@@ -171,13 +171,16 @@ class SpikeFrontEnd:
     def will_fuse(self) -> bool:
         """Whether `encode()` takes the one-launch route by default.  ONE decision for `encode()` and for
         `pipeline.HotPath`, which hands its own raster buffers to the fused launch only.  Gammatone: up to 1024 filters
-        (`lsm_gammatone_spikes_f64`); mel: while the clip's raster stage fits the kernel's LDS (`lsm_mel_spikes_f32`, about
-        600 filters at the reference's 4 thresholds x 100 bins).
+        (`lsm_gammatone_spikes_f64`).  Mel: the one-launch route (`lsm_mel_spikes_f32`, `encode(fused=True)`) exists and
+        gives the same rasters, but measured slower than the three split launches at the reference's CPU-runnable shape
+        (40 filters, 200 clips: 0.318 against 0.305 ms per step, profiles/r04_mel_one_launch_ab.txt), so it is taken by
+        default only with LSM_MEL_ONE_LAUNCH=1.
         LSM_FRONTEND_SPLIT=1: diagnostic switch for same-box A/B runs of the two routes (exp/r03_fused_sweep.sh)."""
         if os.environ.get("LSM_FRONTEND_SPLIT") == "1":
             return False
         if self.filterbank == "mel":
-            return self._mel.fits_one_launch(self.time_bins, len(self.thresholds))
+            return (os.environ.get("LSM_MEL_ONE_LAUNCH") == "1"
+                    and self._mel.fits_one_launch(self.time_bins, len(self.thresholds)))
         return self.n_filters <= 1024
 
     def new_workspace(self, n_clips: int) -> torch.Tensor:
@@ -237,9 +240,10 @@ class SpikeFrontEnd:
 
     def encode(self, audio, fused: bool | None = None, low_latency: bool = False,
                raster_out: torch.Tensor | None = None, workspace: torch.Tensor | None = None) -> torch.Tensor:
-        """audio (B, n_samples) -> uint8 spike raster (B, C, n_steps) on the device.  One launch on both branches
-        (`lsm_gammatone_spikes_f64` / `lsm_mel_spikes_f32`); `fused=False` takes the split entry points (identical
-        rasters), which is also what filterbanks too wide for the one-launch kernels use (`will_fuse()`).  `low_latency`: the
+        """audio (B, n_samples) -> uint8 spike raster (B, C, n_steps) on the device.  The gammatone branch is one
+        launch (`lsm_gammatone_spikes_f64`); `fused=False` takes the split entry points (identical rasters), which is
+        also what the mel branch takes by default (its one-launch route, `fused=True` -> `lsm_mel_spikes_f32`, measured
+        slower) and what filterbanks too wide for the one-launch kernels use (`will_fuse()`).  `low_latency`: the
         fused launch in its one-chain layout (twice the waves, each half as long) -- for a batch that meets an idle
         GPU; `pipeline.HotPath` asks for it when none of its front ends is in flight.  `raster_out` / `workspace`
         (fused launch only): caller-owned uint8 (B, C, n_steps) output and scratch from `new_workspace(B)` (gammatone:

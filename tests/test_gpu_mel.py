@@ -83,31 +83,35 @@ def test_one_launch_mel_front_end_equals_the_three_launch_route(n_mels, redundan
     import torch
     from lsm_speech_classifier_amd import frontend
     fe = frontend.SpikeFrontEnd(n_mels, "mel", redundancy=redundancy, thresholds=thr, gap=gap)
-    assert fe.will_fuse()
+    assert not fe.will_fuse()                              # measured slower than the split launches: opt-in
     audio = _audio(9, seed=n_mels)
     audio[3] = 0.0
     dev = torch.from_numpy(audio).cuda()
-    split = fe.encode(dev, fused=False)
+    split = fe.encode(dev)
+    assert torch.equal(split, fe.encode(dev, fused=False))
     for rep in range(3):                                   # the same cached workspace every time
-        fused = fe.encode(dev)
+        fused = fe.encode(dev, fused=True)
         assert fused.shape == (9, n_mels * redundancy, 100 * len(thr)) and torch.equal(fused, split), rep
     assert split.any() and not split[3].any()
     for n in (1, 2, 5):
-        assert torch.equal(fe.encode(dev[:n]), split[:n])
+        assert torch.equal(fe.encode(dev[:n], fused=True), split[:n])
+    big = torch.from_numpy(np.resize(audio, (140, audio.shape[1]))).cuda()     # >= 128 clips: one workgroup per clip
+    assert torch.equal(fe.encode(big, fused=True), fe.encode(big, fused=False))
     ws = fe.new_workspace(9)
     out = torch.empty_like(split)
-    assert fe.encode(dev, raster_out=out, workspace=ws) is out and torch.equal(out, split)
+    assert fe.encode(dev, fused=True, raster_out=out, workspace=ws) is out and torch.equal(out, split)
     torch.cuda.synchronize()
     assert not ws[:9 * 4].any()                            # counters back at zero
     with pytest.raises(ValueError):
-        fe.encode(dev, workspace=torch.zeros(16, dtype=torch.uint8, device="cuda"))
+        fe.encode(dev, fused=True, workspace=torch.zeros(16, dtype=torch.uint8, device="cuda"))
 
 
-def test_mel_filterbanks_too_wide_for_one_launch_take_the_split_route():
+def test_mel_filterbanks_too_wide_for_one_launch_take_the_split_route(monkeypatch):
     import torch
     from lsm_speech_classifier_amd import frontend, synth
+    monkeypatch.setenv("LSM_MEL_ONE_LAUNCH", "1")
     fe = frontend.SpikeFrontEnd(700, "mel")
-    assert not fe.will_fuse()
+    assert not fe.will_fuse()                               # even when asked for: the raster stage does not fit
     audio = synth.class_chirps([0, 4], seed=5)
     r = fe.encode(audio)                                    # split route, silently
     assert r.shape == (2, 700, 400) and r.any()
@@ -115,10 +119,15 @@ def test_mel_filterbanks_too_wide_for_one_launch_take_the_split_route():
         fe.encode(audio, fused=True)
 
 
-def test_hotpath_with_the_mel_front_end_equals_the_serial_path():
-    """cfg1's shape through the overlapped pipeline: front ends on streams of their own, each with its OWN workspace (two
-    launches sharing the arrival counters would finish each other's clips), rows equal to the serial path."""
+@pytest.mark.parametrize("one_launch", [True, False])
+def test_hotpath_with_the_mel_front_end_equals_the_serial_path(monkeypatch, one_launch):
+    """cfg1's shape through the overlapped pipeline on both mel routes.  One launch (LSM_MEL_ONE_LAUNCH=1): front ends on
+    streams of their own, each with its OWN workspace (two launches sharing the arrival counters would finish each other's
+    clips); split launches (the default): rasters from the allocator, handed over with record_stream.  Rows equal to the
+    serial path either way."""
     import torch
+    if one_launch:
+        monkeypatch.setenv("LSM_MEL_ONE_LAUNCH", "1")
     from lsm_speech_classifier_amd import frontend, pipeline, reservoir as R, snn, synth
     from oracle import ref_numpy as O
     keys = ['spike_counts', 'spike_variances', 'mean_spike_times', 'mean_isi', 'isi_variances']
@@ -134,4 +143,8 @@ def test_hotpath_with_the_mel_front_end_equals_the_serial_path():
         hp = pipeline.HotPath(fe, net, keys, streams=streams, fe_streams=fes)
         for rep in range(3):
             assert torch.equal(hp.run(batches), serial), (streams, fes, rep)
-    assert len({w.data_ptr() for w in hp._ws.values()}) == len(hp._ws) >= 2
+    assert fe.will_fuse() == one_launch
+    if one_launch:
+        assert len({w.data_ptr() for w in hp._ws.values()}) == len(hp._ws) >= 2
+    else:
+        assert not hp._ws
