@@ -500,14 +500,18 @@ void lif_ring_kernel(const RingArgs a)
             for (int h = 0; h < 4; ++h) {
                 const int r = 4 * q + h;
                 ci[h] = ci[h] + w_in * (float)nn[h];       // SPEC.md §3: input term after the recurrent sum
-                const bool held = oref[r] >= 0x10000u;
                 const float m = lam[r] * v[r];
                 const float d = v[r] - m;
                 const float vn = d + ci[h];
-                const bool fire = !held && (vn >= theta);
-                v[r] = (held || fire) ? 0.0f : vn;
-                oref[r] += held ? 0xFFFF0000u : (fire ? ref_set : 0u);
-                bq[h] = __ballot(fire);
+                // lane masks straight from the compares (round 4, as in lif_dense.h): `held`, `fire` and the reset's
+                // select are scalar mask arithmetic + one v_cndmask; a ballot of a materialised boolean costs two more
+                const unsigned long long held = __builtin_amdgcn_uicmp(oref[r], 0x10000u, 35 /* unsigned >= */);
+                const unsigned long long ge = __builtin_amdgcn_fcmpf(vn, theta, 3 /* ordered >= */);
+                const unsigned long long fire = ge & ~held;
+                v[r] = __builtin_amdgcn_inverse_ballot_w64(ge | held) ? 0.0f : vn;
+                oref[r] += __builtin_amdgcn_inverse_ballot_w64(held) ? 0xFFFF0000u
+                           : (__builtin_amdgcn_inverse_ballot_w64(fire) ? ref_set : 0u);
+                bq[h] = fire;
             }
             int nq = 0;
             if ((bq[0] | bq[1] | bq[2] | bq[3]) != 0ull) {
@@ -516,7 +520,7 @@ void lif_ring_kernel(const RingArgs a)
 #pragma unroll
                 for (int h = 0; h < 4; ++h) {
                     const int r = 4 * q + h;
-                    if ((bq[h] >> lane) & 1ull) {
+                    if (__builtin_amdgcn_inverse_ballot_w64(bq[h])) {
                         list_cur[gq * 256 + rank] = (uint16_t)(gq * 256 + lane * 4 + h);
                         rank += 1;
                         hf |= 1u << r;
