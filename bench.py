@@ -602,8 +602,11 @@ def run_rank(args):
                 "weight_table_bytes": plan["table_bytes"], "gather_ceiling": ceiling, "gather_ceiling_note": ceiling_note,
                 "row_gather": None if lone_ms is None or spikes_total is None else {
                     "rows_per_launch": spikes_total, "mean_row_bytes": round(row_bytes, 1),
+                    "requested_bytes": int(spikes_total * row_bytes),
                     "gbs_lone_launch": round(spikes_total * row_bytes / (lone_ms * 1e-3) / 1e9, 1),
-                    "frac_of_gather_ceiling": round(spikes_total * row_bytes / (lone_ms * 1e-3) / 1e9 / ceiling, 4),
+                    # > 1: the L2s serve the rest of the requests; this is a REQUEST rate, so it is not set against the
+                    # memory-side ceiling (that is memory_side_frac's job: r03's cfg5 line read 1.22 for this reason)
+                    "requested_over_memory_side": None if traffic is None else round(spikes_total * row_bytes / traffic, 3),
                     "note": "reservoir spikes of the batch (stats_out of one untimed launch) x the bytes ONE spike requests "
                             "from the table in use (lsm_reservoir_row_request_bytes: the window's existing bytes + its list "
                             "entries + row pointers, mean over rows; table padding is not charged) / lone-launch time"},

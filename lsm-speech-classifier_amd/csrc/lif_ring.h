@@ -145,7 +145,10 @@ void lif_ring_kernel(const RingArgs a)
 #ifndef LSM_RING_PC
 #define LSM_RING_PC (QL >= 4 ? 4 : 8)
 #endif
-    constexpr int P = STRIDED ? LSM_RING_P : LSM_RING_PC;   // rows in flight (WL*4 + 2 registers each), even
+    // rows in flight (WL*4 + 2 registers each), even.  Round 4, after the update's lane masks freed registers: four quads per
+    // wave (N = 8000) take 6 -- 142 registers, still three waves per SIMD: cfg5 163.2 -> 160.4 ms --, two quads keep 4
+    // (N = 4000 with 6: 6.02 -> 6.23 ms; profiles/r04_ring_masks_and_rows_in_flight.txt)
+    constexpr int P = STRIDED ? (QL == 4 && LSM_RING_P == 4 ? 6 : LSM_RING_P) : LSM_RING_PC;
     constexpr uint32_t RSRC_FLAGS = 0x00020000u;    // raw dword buffer, gfx9 family
     static_assert(NQP <= RING_MAX_QUADS, "at most 8192 neurons");
 

@@ -70,7 +70,9 @@ def test_bench_line_contract():
     assert r["traffic"] is None and r["traffic_source"].startswith("none:") and "cfg2_B64_dense" in r["traffic_source"]
     assert r["gather_ceiling"] == 16800.0 and 4e6 < r["weight_table_bytes"] < 4.5e6      # 1000 x 1024 x 4: L2 resident
     g = r["row_gather"]
-    assert g["rows_per_launch"] > 0 and 0 < g["frac_of_gather_ceiling"] < 1 and g["mean_row_bytes"] == 4096.0
+    assert g["rows_per_launch"] > 0 and g["mean_row_bytes"] == 4096.0 and g["requested_over_memory_side"] is None
+    assert g["requested_bytes"] == g["rows_per_launch"] * 4096 and g["gbs_lone_launch"] > 0
+    assert not any("frac" in k for k in g)              # a request rate is not a fraction of the memory-side ceiling
     assert r["memory_side_frac"] is None
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["cores"] == 1 and c["unit"] == "clips/s" and c["value"] > 0 and c["sample"]
@@ -114,3 +116,4 @@ def test_fractions_of_the_large_configs_stay_within_one(config, batch):
     r = d["roofline"]
     assert r["kernel"] == "lif_ring_kernel" and r["row_gather"]["mean_row_bytes"] * d["config"]["num_neurons"] \
         <= r["weight_table_bytes"]
+    assert r["row_gather"]["gbs_lone_launch"] > 0
