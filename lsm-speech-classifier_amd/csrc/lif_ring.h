@@ -84,6 +84,9 @@ struct RingArgs {
     const float *leak;         // (NPAD), neuron order
     const int *oslot;          // (NPAD) output slot or -1, neuron order
     const uint32_t *in_ent;    // (WPC, EinW) packed entries (ring_pack_entry), EinW a multiple of RING_ENT_BLOCK, padded with dump-word entries
+    const uint32_t *inmask;    // INMASK: (NPAD, 4) input-channel bit mask per neuron, neuron order (C <= 128), else null
+    const uint8_t *inperm;     // INMASK with coloured positions: (C) bit position of channel c in the input bit row, else null
+    float leak_u;              // INMASK: the one leak coefficient of every neuron (the kernel form exists for uniform leaks)
     int n_keys;
     int key_ids[8];
     float *features;           // (B, n_keys * n_out)
@@ -130,7 +133,12 @@ __host__ __device__ inline int ring_cnt_word(int i) { return RING_DUMP_WORDS + (
 // every step; STRIDED: quad ownership (see above).
 // (Up to two quads per wave the strided kernel must keep four waves per SIMD -- 128 registers -- whatever it holds in
 // registers: two clips per CU is what its LDS image allows, and that is 16 waves.)
-template <int QL, int WPC, bool INREG, bool STRIDED>
+// INMASK (round 4; 0 = off, 1 = natural bit positions, 2 = coloured positions): the input drive as in the dense kernel's INMODE
+// 2 / 3 -- every neuron holds the bit mask of its input channels in four registers and counts popcount(mask & row) in the update;
+// no input-map entries, no LDS atomics, no count array on the step's critical path (the entry drive cost ~1.0 of cfg4's 6.0 ms,
+// profiles/r04_ring_input_drive.txt).  The 4 x SL registers exist only when the leak coefficients do not need SL of their own:
+// offered for UNIFORM leaks (the reference's default, leak_variance_divisor = None), C <= 128 and at most two quads per wave.
+template <int QL, int WPC, bool INREG, bool STRIDED, int INMASK = 0>
 __global__ __launch_bounds__(WPC * 64) __attribute__((amdgpu_waves_per_eu((QL <= 2 && STRIDED) ? 4 : 1)))
 void lif_ring_kernel(const RingArgs a)
 {
@@ -184,17 +192,19 @@ void lif_ring_kernel(const RingArgs a)
                 if (v == 0) continue;
                 const int c = (q * 4) / T;
                 const int t0 = (q * 4) - c * T;
-                const uint32_t bit = 1u << (c & 31);
+                const int pc = INMASK == 2 ? (int)a.inperm[c] : c;      // the channel's place in the bit row
+                const uint32_t bit = 1u << (pc & 31);
 #pragma unroll
                 for (int k = 0; k < 4; ++k)
-                    if ((v >> (8 * k)) & 0xFFu) atomicOr(&bits[(t0 + k) * CW + (c >> 5)], bit);
+                    if ((v >> (8 * k)) & 0xFFu) atomicOr(&bits[(t0 + k) * CW + (pc >> 5)], bit);
             }
         } else {
             const int nb = a.C * T;
             for (int q = tid; q < nb; q += NT)
                 if (clip[q]) {
                     const int c = q / T;
-                    atomicOr(&bits[(q - c * T) * CW + (c >> 5)], 1u << (c & 31));
+                    const int pc = INMASK == 2 ? (int)a.inperm[c] : c;
+                    atomicOr(&bits[(q - c * T) * CW + (pc >> 5)], 1u << (pc & 31));
                 }
         }
     }
@@ -202,12 +212,14 @@ void lif_ring_kernel(const RingArgs a)
     // my neurons: register r = 4*q + h  <->  neuron GQ(q)*256 + lane*4 + h
     // oref[r] = (output slot + 1) | (refractory countdown << 16): one register for both, "held" is one
     // unsigned compare, the slot is unpacked only when the neuron fires.
-    float v[SL], lam[SL];
+    float v[SL], lam[INMASK ? 1 : SL];
     uint32_t oref[SL];
+    uint32_t im[INMASK ? SL : 1][4];              // INMASK: channels 0..127 feeding my neuron r
+    const float lam_u = a.leak_u;
 #pragma unroll
     for (int q = 0; q < QL; ++q) {
         const int i0 = LSM_RING_GQ(q) * 256 + lane * 4;
-        const float4 l4 = *reinterpret_cast<const float4 *>(a.leak + i0);
+        const float4 l4 = INMASK ? make_float4(0.f, 0.f, 0.f, 0.f) : *reinterpret_cast<const float4 *>(a.leak + i0);
         const int4 o4 = *reinterpret_cast<const int4 *>(a.oslot + i0);
         const float l[4] = {l4.x, l4.y, l4.z, l4.w};
         const int o[4] = {o4.x, o4.y, o4.z, o4.w};
@@ -217,16 +229,20 @@ void lif_ring_kernel(const RingArgs a)
             // threshold test is false for ever -- a window that wraps past the ring's end may deliver weights
             // of real quads to them, and they must never fire
             v[4 * q + h] = (i0 + h) < N ? 0.0f : __builtin_nanf("");
-            lam[4 * q + h] = l[h];
+            if (!INMASK) lam[4 * q + h] = l[h];
             oref[4 * q + h] = (uint32_t)(o[h] + 1);
+            if (INMASK) {
+                const uint4 m = reinterpret_cast<const uint4 *>(a.inmask)[i0 + h];
+                im[4 * q + h][0] = m.x; im[4 * q + h][1] = m.y; im[4 * q + h][2] = m.z; im[4 * q + h][3] = m.w;
+            }
         }
     }
     const uint32_t ref_set = (uint32_t)a.refractory << 16;
     const float theta = a.theta, w_in = a.w_in;
     const uint32_t *my_ent = a.in_ent + (size_t)w * a.EinW;            // EinW: a multiple of RING_ENT_BLOCK
     constexpr int EPL = RING_ENT_BLOCK / 64;                            // entries per lane and block
-    uint32_t ent_reg[INREG ? EPL * RING_ENT_REG_BLOCKS : 1];            // INREG: the wave's whole map, resident
-    if (INREG) {
+    uint32_t ent_reg[(INREG && !INMASK) ? EPL * RING_ENT_REG_BLOCKS : 1];   // INREG: the wave's whole map, resident
+    if (INREG && !INMASK) {
 #pragma unroll
         for (int u = 0; u < EPL * RING_ENT_REG_BLOCKS; ++u) ent_reg[u] = my_ent[u * 64 + lane];
     }
@@ -275,6 +291,7 @@ void lif_ring_kernel(const RingArgs a)
         }
     };
     auto input_drive = [&](int ts, uint32_t keep = 0xFFFFFFFFu) {
+        if (INMASK) return;                       // counted in the update, from the masks
         const uint32_t *row = bits + ts * CW;
         if (INREG) {
 #pragma unroll
@@ -484,6 +501,16 @@ void lif_ring_kernel(const RingArgs a)
         }
         drive_once();                  // a step without reservoir spikes: no rows to hide behind
         wave_lds_fence();
+        uint32_t rowbits[4] = {0u, 0u, 0u, 0u};              // INMASK: this step's input bit row (wave-uniform)
+        if (INMASK) {
+            if (CW == 4) {
+                const uint4 q4 = *reinterpret_cast<const uint4 *>(bits + t * 4);
+                rowbits[0] = q4.x; rowbits[1] = q4.y; rowbits[2] = q4.z; rowbits[3] = q4.w;
+            } else {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) rowbits[k] = k < CW ? bits[t * CW + k] : 0u;
+            }
+        }
 
         // ---- neuron update, quad by quad: leak/integrate/threshold by select, then (only if a neuron of the
         //      quad fired) its entries of the quad's spike list and the feature accumulators ----
@@ -494,16 +521,35 @@ void lif_ring_kernel(const RingArgs a)
             // my four recurrent sums and input counts of this quad; both arrays are cleared for the next step
             const ring_f4 cq = *reinterpret_cast<const ring_f4 *>(smem + acc_b + (uint32_t)gq * 1024u);
             *reinterpret_cast<ring_f4 *>(smem + acc_b + (uint32_t)gq * 1024u) = (ring_f4){0.0f, 0.0f, 0.0f, 0.0f};
-            const ring_u2 nin = *reinterpret_cast<const ring_u2 *>(smem + cnt_b + (uint32_t)gq * 512u);
-            *reinterpret_cast<ring_u2 *>(smem + cnt_b + (uint32_t)gq * 512u) = (ring_u2){0u, 0u};
-            const uint32_t nn[4] = {nin.x & 0xFFFFu, nin.x >> 16, nin.y & 0xFFFFu, nin.y >> 16};
+            uint32_t nn[4];
+            if (INMASK) {
+#pragma unroll
+                for (int h = 0; h < 4; ++h) {
+                    const int r = 4 * q + h;
+                    if (INMASK == 2) {
+                        // disjoint by construction of the bit positions: one popcount of the union (lif_dense.h, INMODE 3)
+                        uint32_t u = im[r][0] & rowbits[0];
+#pragma unroll
+                        for (int k = 1; k < 4; ++k)
+                            asm("v_and_or_b32 %0, %1, %2, %0" : "+v"(u) : "v"(im[r][k]), "v"(rowbits[k]));
+                        nn[h] = __popc(u);
+                    } else {
+                        nn[h] = __popc(im[r][0] & rowbits[0]) + __popc(im[r][1] & rowbits[1]) +
+                                __popc(im[r][2] & rowbits[2]) + __popc(im[r][3] & rowbits[3]);
+                    }
+                }
+            } else {
+                const ring_u2 nin = *reinterpret_cast<const ring_u2 *>(smem + cnt_b + (uint32_t)gq * 512u);
+                *reinterpret_cast<ring_u2 *>(smem + cnt_b + (uint32_t)gq * 512u) = (ring_u2){0u, 0u};
+                nn[0] = nin.x & 0xFFFFu; nn[1] = nin.x >> 16; nn[2] = nin.y & 0xFFFFu; nn[3] = nin.y >> 16;
+            }
             float ci[4] = {cq.x, cq.y, cq.z, cq.w};
             unsigned long long bq[4];
 #pragma unroll
             for (int h = 0; h < 4; ++h) {
                 const int r = 4 * q + h;
                 ci[h] = ci[h] + w_in * (float)nn[h];       // SPEC.md §3: input term after the recurrent sum
-                const float m = lam[r] * v[r];
+                const float m = (INMASK ? lam_u : lam[r]) * v[r];
                 const float d = v[r] - m;
                 const float vn = d + ci[h];
                 // lane masks straight from the compares (round 4, as in lif_dense.h): `held`, `fire` and the reset's
@@ -635,10 +681,32 @@ ring_fn_t pick_ring(int wpc, bool inreg, bool strided)
     return inreg ? pick_ring_wpc<QL, true, false>(wpc) : pick_ring_wpc<QL, false, false>(wpc);
 }
 
+// INMASK forms: strided ownership, at most two quads per wave (lif_ring_1.hip, lif_ring_2.hip); inmask = 1 natural / 2 coloured
+template <int QL, int INMASK>
+ring_fn_t pick_ring_mask_wpc(int wpc)
+{
+    switch (wpc) {
+    case 2: return lif_ring_kernel<QL, 2, false, true, INMASK>;
+    case 4: return lif_ring_kernel<QL, 4, false, true, INMASK>;
+    case 8: return lif_ring_kernel<QL, 8, false, true, INMASK>;
+    case 16:
+        if constexpr (QL * 16 <= RING_MAX_QUADS) return lif_ring_kernel<QL, 16, false, true, INMASK>;
+        else return nullptr;
+    default: return nullptr;
+    }
+}
+template <int QL>
+ring_fn_t pick_ring_mask(int wpc, int inmask)
+{
+    return inmask == 2 ? pick_ring_mask_wpc<QL, 2>(wpc) : pick_ring_mask_wpc<QL, 1>(wpc);
+}
+
 // one definition per translation unit lif_ring_<ql>.hip
 ring_fn_t pick_ring_1(int wpc, bool inreg, bool strided);
 ring_fn_t pick_ring_2(int wpc, bool inreg, bool strided);
 ring_fn_t pick_ring_3(int wpc, bool inreg, bool strided);
 ring_fn_t pick_ring_4(int wpc, bool inreg, bool strided);
+ring_fn_t pick_ring_mask_1(int wpc, int inmask);
+ring_fn_t pick_ring_mask_2(int wpc, int inmask);
 
 }  // namespace lsm_lif

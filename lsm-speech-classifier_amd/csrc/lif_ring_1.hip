@@ -3,4 +3,5 @@
 
 namespace lsm_lif {
 ring_fn_t pick_ring_1(int wpc, bool inreg, bool strided) { return pick_ring<1>(wpc, inreg, strided); }
+ring_fn_t pick_ring_mask_1(int wpc, int inmask) { return pick_ring_mask<1>(wpc, inmask); }
 }  // namespace lsm_lif

@@ -57,7 +57,10 @@ struct RingVariant {        // per waves-per-clip layout of the ring-row kernel 
     uint2 *rem = nullptr;            // synapses outside the ring window: {LDS byte offset of the accumulator, weight bits}
     float *leak = nullptr;
     int *oslot = nullptr;
-    uint32_t *in_ent = nullptr;      // (wpc, einw) (channel << 16) | target neuron
+    uint32_t *in_ent = nullptr;      // (wpc, einw) packed input-map entries (lsm_lif::ring_pack_entry)
+    uint32_t *inmask = nullptr;      // (npad, 4) input-channel masks in neuron order: the INMASK kernel form (C <= 128, uniform
+                                     // leak, strided ownership, <= 2 quads per wave), else null
+    bool incol = false;              // the masks use the coloured bit positions of lsm_reservoir::inperm
 };
 
 }  // namespace
@@ -94,6 +97,8 @@ struct lsm_reservoir {
     // channels feeding one neuron sit at different positions mod 32 (colour_input_channels); null when no such
     // assignment was found (then the masks keep the natural positions, INMODE 2)
     uint8_t *inperm = nullptr;
+    bool leak_uniform = false;       // every neuron has the same leak coefficient (leak_u): the reference's default
+    float leak_u = 0.0f;
     int mode = 0;           // 0 auto, 1 sparse (CSC scatter through LDS), 2 dense rows, 3 ring rows,
                             // 4 ring rows with contiguous quad ownership only (tests)
     Variant var[5];         // wpc = 1, 2, 4, 8, 16 (wpc == 0: not available)
@@ -119,6 +124,7 @@ static int free_reservoir(lsm_reservoir *h)
     for (auto &v : h->rvar) {
         if (v.rem_ptr) (void)hipFree(v.rem_ptr);
         if (v.rem) (void)hipFree(v.rem);
+        if (v.inmask) (void)hipFree(v.inmask);
         if (v.leak) (void)hipFree(v.leak);
         if (v.oslot) (void)hipFree(v.oslot);
         if (v.in_ent) (void)hipFree(v.in_ent);
@@ -316,6 +322,10 @@ int lsm_reservoir_create(lsm_reservoir **out, int num_neurons, int n_channels,
 #endif
     const bool coloured = !no_incol && colour_input_channels(N, C, in_tgt, in_fanout, &inperm);
     if (coloured && (rc = upload(&h->inperm, inperm))) { free_reservoir(h); return rc; }
+    h->leak_uniform = true;
+    h->leak_u = leak[0];
+    for (int i = 1; i < N; ++i)
+        if (std::memcmp(&leak[i], &leak[0], sizeof(float)) != 0) { h->leak_uniform = false; break; }
 
     const int wpcs[5] = {1, 2, 4, 8, 16};
     for (int vi = 0; vi < 5; ++vi) {
@@ -510,6 +520,28 @@ int lsm_reservoir_create(lsm_reservoir **out, int num_neurons, int n_channels,
                         (rc = upload(&v.oslot, os)) || (rc = upload(&v.in_ent, ent))) {
                         free_reservoir(h);
                         return rc;
+                    }
+                    // INMASK form of the kernel (lif_ring.h): per-neuron channel masks in registers instead of the entry drive
+#if LSM_EXPERIMENT_HOOKS
+                    static const bool no_ring_mask = [] { const char *e = getenv("LSM_RING_NO_INMASK"); return e && atoi(e) != 0; }();
+#else
+                    constexpr bool no_ring_mask = false;
+#endif
+                    if (!no_ring_mask && C <= 128 && h->leak_uniform && strided && ql <= 2) {
+                        std::vector<uint32_t> im((size_t)npad * 4, 0u);
+                        bool distinct = true;
+                        for (int c = 0; c < C; ++c)
+                            for (int d = 0; d < in_fanout; ++d) {
+                                const int tgt = in_tgt[(size_t)c * in_fanout + d];
+                                const int pc = coloured ? inperm[c] : c;
+                                uint32_t &word = im[(size_t)tgt * 4 + (pc >> 5)];
+                                distinct = distinct && !(word & (1u << (pc & 31)));
+                                word |= 1u << (pc & 31);
+                            }
+                        if (distinct) {
+                            if ((rc = upload(&v.inmask, im))) { free_reservoir(h); return rc; }
+                            v.incol = coloured;
+                        }
                     }
                     v.wpc = wpc; v.ql = ql; v.einw = einw; v.strided = strided; v.n_rem = rptr.back();
                 }
@@ -825,7 +857,10 @@ static int reservoir_run(const lsm_reservoir *h, const uint8_t *spikes_u8, int n
     if (plan.kernel == 3) {
         const RingVariant *rv = plan.rv;
         const bool inreg = ring_inreg(*rv);
-        lsm_lif::ring_fn_t rfn = rv->ql == 1   ? lsm_lif::pick_ring_1(rv->wpc, inreg, rv->strided)
+        const bool inmask = rv->inmask != nullptr;
+        lsm_lif::ring_fn_t rfn = inmask ? (rv->ql == 1 ? lsm_lif::pick_ring_mask_1(rv->wpc, rv->incol ? 2 : 1)
+                                                       : lsm_lif::pick_ring_mask_2(rv->wpc, rv->incol ? 2 : 1))
+                                 : rv->ql == 1 ? lsm_lif::pick_ring_1(rv->wpc, inreg, rv->strided)
                                  : rv->ql == 2 ? lsm_lif::pick_ring_2(rv->wpc, inreg, rv->strided)
                                  : rv->ql == 3 ? lsm_lif::pick_ring_3(rv->wpc, inreg, rv->strided)
                                                : lsm_lif::pick_ring_4(rv->wpc, inreg, rv->strided);
@@ -838,6 +873,7 @@ static int reservoir_run(const lsm_reservoir *h, const uint8_t *spikes_u8, int n
         r.theta = h->theta; r.w_in = h->w_in;
         r.raster = spikes_u8; r.band = h->band; r.rem_ptr = rv->rem_ptr; r.rem = rv->rem;
         r.leak = rv->leak; r.oslot = rv->oslot; r.in_ent = rv->in_ent;
+        r.inmask = rv->inmask; r.inperm = (inmask && rv->incol) ? h->inperm : nullptr; r.leak_u = h->leak_u;
         r.n_keys = n_keys;
         for (int k = 0; k < 8; ++k) r.key_ids[k] = k < n_keys ? key_ids[k] : 0;
         r.features = features_out; r.spike_matrix = spike_matrix_out; r.v_trace = v_trace_out;
@@ -963,7 +999,7 @@ int lsm_reservoir_input_mode(const lsm_reservoir *h, int n_clips, int n_steps, i
     if (h == nullptr) return LSM_ERR_ARG;
     RunPlan p;
     if (make_plan(h, n_clips, n_steps, waves_per_clip, &p) != LSM_OK) return LSM_ERR_UNSUPPORTED;
-    if (p.kernel == 3) return ring_inreg(*p.rv) ? 11 : 10;
+    if (p.kernel == 3) return p.rv->inmask ? (p.rv->incol ? 13 : 12) : (ring_inreg(*p.rv) ? 11 : 10);
     if (p.kernel == 1) return 20;
     return p.v->inmask ? (p.v->incol ? 3 : 2) : (lif_inreg(*p.v) ? 1 : 0);
 }

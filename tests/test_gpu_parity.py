@@ -415,6 +415,27 @@ def test_oracle_on_a_reservoir_it_did_not_build(torch_cuda, oracle_c):
     np.testing.assert_array_equal(vt_np, vt_c)
 
 
+@pytest.mark.parametrize("divisor,channels", [(None, 128), (5.0, 128), (None, 200), (None, 40)])
+def test_ring_rows_count_inputs_from_masks_or_entries(torch_cuda, oracle_c, divisor, channels):
+    """Round 4: with one leak coefficient for every neuron (the reference's default, extract_lsm_features.py:174 passes
+    leak_variance_divisor=None) and at most 128 channels the ring kernel keeps per-neuron channel masks in registers and
+    counts the input drive in the update (input modes 12 / 13); heterogeneous leaks need those registers and more than 128
+    channels need more mask words: both keep the packed input-map entries (modes 10 / 11).  Same results either way."""
+    from lsm_speech_classifier_amd import snn, synth
+    n, k, t = 4096, 300, 90
+    rasters = synth.bernoulli_raster(2, channels, t, 0.25, seed=channels)
+    kw = {} if divisor is None else {"leak_variance_divisor": divisor}
+    res = _reservoir(n, k, n // 3, channels, rasters, **kw)
+    net = snn.SNN(None, reservoir=res)
+    net.set_kernel("ring")
+    mode = net.plan(2, t, 8)["input_mode"]
+    assert mode in ((12, 13) if divisor is None and channels <= 128 else (10, 11)), mode
+    ran = 0
+    for wpc in (0, 8, 16):
+        ran += _check_against_oracle(net, rasters, oracle_c, wpc) > 1
+    assert ran >= 2
+
+
 @pytest.mark.parametrize("hub_channels", [33, 32, 1])
 def test_input_maps_with_and_without_a_mask_colouring(torch_cuda, oracle_c, hub_channels):
     """Round 4: the dense kernel counts a neuron's active inputs with ONE popcount when the library finds bit positions
