@@ -68,7 +68,12 @@ int lsm_gammatone_spec_f64(const float *audio, int n_clips, int n_samples, const
  *               8-byte aligned, owned by the caller, contents undefined before and after the call
  *   launch_flags bit 0: low-latency layout -- one channel group per wave instead of two: twice the waves, each half
  *               as long (for a launch onto an idle GPU: 1.47 instead of 2.43 ms per 256 clips x 128 filters, 12 % more
- *               CU time).  Results do not depend on it.  0 = the throughput layout.
+ *               CU time); above 512 filters the flag is ignored (the one-chain layout would need more than 8 waves
+ *               per clip).  bit 1: no LDS reservation -- a launch of at most one workgroup per CU normally reserves
+ *               half a CU's LDS so that overlapping launches spread one workgroup per CU; beside a kernel whose
+ *               workgroups need most of the LDS themselves (the ring-row reservoir kernel) the caller sets this bit and
+ *               the launch asks for what it uses (27 KB per 4-wave workgroup at 4 thresholds x 100 bins).
+ *               Results do not depend on the flags.  0 = the throughput layout with the reservation.
  * Returns LSM_ERR_UNSUPPORTED for more than 1024 filters (use the two split entry points). */
 long lsm_gammatone_spikes_workspace(int n_clips, int n_filters, int ncols);
 int lsm_gammatone_spikes_f64(const float *audio, int n_clips, int n_samples, const double *coefs_dev,

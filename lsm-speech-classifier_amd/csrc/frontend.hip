@@ -374,16 +374,19 @@ __global__ __launch_bounds__(GT_MAX_WPB * 64) void gammatone_spikes_kernel(const
     const unsigned long long den_bits = (unsigned long long)__double_as_longlong(den);
     const bool fastdiv = den > 1e-200 && den < 1e200 &&
                          (den_bits & 0x000FFFFFFFFFFFFFull) != 0x000FFFFFFFFFFFFFull;
-    // Pass A (no dependency between bins, the loads of a whole group of bins in flight together): per bin j and
-    // threshold t the two comparisons the latch needs, S = val > on[t] in bit t and R = val < off[t] in bit FBH + t
-    // of the bin's field; JPW fields per LDS word of the lane's row.  Pass B (serial in j, LDS only) runs the
-    // set/reset latches of all thresholds at once, A = (S & ~A) | (A & ~R), and packs the raster bits IN PLACE: the
-    // raster word of bin j lies at or below the field word of bin j in the same row.  Fields of bins >= Tb in the
-    // last word repeat the last bin and are never read.
+    // Per group of JPW bins (no dependency between the bins of a group, the loads of the whole group in flight together):
+    // per bin j and threshold t the two comparisons the latch needs, S = val > on[t] in bit t and R = val < off[t] in bit
+    // FBH + t of the bin's field; then -- round 4: in the same iteration, from registers -- the set/reset latches of all
+    // thresholds at once, A = (S & ~A) | (A & ~R), and the raster bits appended to a 64-bit accumulator that is stored to
+    // the lane's LDS row a word at a time.  The first version staged the FIELDS of all bins in LDS (pass A) and ran the
+    // latch as a second pass over them (pass B): 100 bytes of stage per channel instead of 50, i.e. 51 KB instead of
+    // 27 KB per 4-wave workgroup -- which mattered once a ring-kernel clip pair (2 x 64 KB) had to fit beside it on a CU.
+    // The only state carried from group to group is the latch (4-8 bits per chain) and the bit accumulator.
     const int FBH = n_thr <= 4 ? 4 : 8;                 // bits per half field
     const int JPW = 16 / FBH;                           // bins per 32-bit word (4 or 2)
-    const int BW = (Tb + JPW - 1) / JPW;                // words per lane row (>= raster words per row)
-    uint32_t *stage = stage_all + (size_t)wave * (NCH * 64) * BW;
+    const int NG4 = (Tb + JPW - 1) / JPW;               // groups of JPW bins
+    const int RW = (row_bits + 31) >> 5;                // words per staged raster row
+    uint32_t *stage = stage_all + (size_t)wave * (NCH * 64) * RW;
     const size_t cs = (size_t)NG * 64;                  // doubles between two columns of the scratch
     // straight-line variants (fast division or not, <= 4 thresholds or not, resize or not): one uniform choice
     // per wave instead of uniform branches inside the loop, which would keep the compiler from batching the loads
@@ -404,8 +407,14 @@ __global__ __launch_bounds__(GT_MAX_WPB * 64) void gammatone_spikes_kernel(const
 #ifndef LSM_GTF_PASS_A_UNROLL
 #define LSM_GTF_PASS_A_UNROLL 1
 #endif
+        uint32_t act[NCH];
+        unsigned long long acc[NCH];
+#pragma unroll
+        for (int q = 0; q < NCH; ++q) { act[q] = 0u; acc[q] = 0ull; }
+        int fill = 0, wout = 0;                         // the same for every chain of the lane
+        const uint32_t tmask_a = (1u << n_thr) - 1u;
 #pragma unroll LSM_GTF_PASS_A_UNROLL
-        for (int jw = 0; jw < BW; ++jw) {
+        for (int jw = 0; jw < NG4; ++jw) {
             double x0[G][NCH], x1[G][NCH], w0[G], w1[G];
             bool two[G];
 #pragma unroll
@@ -452,8 +461,33 @@ __global__ __launch_bounds__(GT_MAX_WPB * 64) void gammatone_spikes_kernel(const
                     fw[q] |= field << (u * 2 * H);
                 }
             }
+            // the latches of this group's bins, in bin order (bins past the last one repeat it and are skipped)
 #pragma unroll
-            for (int q = 0; q < NCH; ++q) stage[(q * 64 + lane) * BW + jw] = fw[q];
+            for (int u = 0; u < G; ++u) {
+                if (jw * G + u < Tb) {                  // wave-uniform
+#pragma unroll
+                    for (int q = 0; q < NCH; ++q) {
+                        const uint32_t field = fw[q] >> (u * 2 * H);
+                        const uint32_t S = field & tmask_a, R = (field >> H) & tmask_a;
+                        act[q] = (S & ~act[q]) | (act[q] & ~R);     // create_dataset.py:90-95 (both from the old latch)
+                        acc[q] |= (unsigned long long)act[q] << fill;
+                    }
+                    fill += n_thr;
+                    if (fill >= 32) {
+#pragma unroll
+                        for (int q = 0; q < NCH; ++q) {
+                            stage[(q * 64 + lane) * RW + wout] = (uint32_t)acc[q];
+                            acc[q] >>= 32;
+                        }
+                        ++wout;
+                        fill -= 32;
+                    }
+                }
+            }
+        }
+        if (fill > 0) {
+#pragma unroll
+            for (int q = 0; q < NCH; ++q) stage[(q * 64 + lane) * RW + wout] = (uint32_t)acc[q];
         }
     };
     {
@@ -470,32 +504,6 @@ __global__ __launch_bounds__(GT_MAX_WPB * 64) void gammatone_spikes_kernel(const
             else         { if (zoom) pass_a(F{}, N8{}, T{}); else pass_a(F{}, N8{}, F{}); }
         }
     }
-    // Pass B: the lane's own rows only, so no barrier: LDS serves one wave's accesses in order
-    const uint32_t tmask = (1u << n_thr) - 1u;
-#pragma unroll
-    for (int q = 0; q < NCH; ++q) {
-        uint32_t *srow = stage + (q * 64 + lane) * BW;
-        uint32_t act = 0u, cur = 0u;
-        unsigned long long acc = 0ull;
-        int fill = 0, wout = 0;
-        for (int j = 0; j < Tb; ++j) {
-            const int u = j % JPW;
-            if (u == 0) cur = srow[j / JPW];
-            const uint32_t field = cur >> (u * 2 * FBH);
-            const uint32_t S = field & tmask, R = (field >> FBH) & tmask;
-            // create_dataset.py:90-95: rising and falling are both taken from the latch BEFORE the update, so an
-            // active latch with S and R both true (only possible when off > on: a negative gap) is cleared
-            act = (S & ~act) | (act & ~R);
-            acc |= (unsigned long long)act << fill;
-            fill += n_thr;
-            if (fill >= 32) {
-                srow[wout++] = (uint32_t)acc;
-                acc >>= 32;
-                fill -= 32;
-            }
-        }
-        if (fill > 0) srow[wout] = (uint32_t)acc;
-    }
     __syncthreads();                                    // the wave's own staged rows (and a uniform barrier count)
     if (valid) {
         // create_pure_redundancy: output row c reads filter row c / redundancy
@@ -510,14 +518,14 @@ __global__ __launch_bounds__(GT_MAX_WPB * 64) void gammatone_spikes_kernel(const
             for (int i = lane; i < rows_out * rw; i += 64) {
                 const int c = i / rw;
                 const int p = (i - c * rw) * 4;
-                const uint32_t nib = (stage[(c / R) * BW + (p >> 5)] >> (p & 31)) & 0xFu;
+                const uint32_t nib = (stage[(c / R) * RW + (p >> 5)] >> (p & 31)) & 0xFu;
                 d4[i] = (nib * 0x00204081u) & 0x01010101u;
             }
         } else {
             for (int i = lane; i < rows_out * row_bytes; i += 64) {
                 const int c = i / row_bytes;
                 const int p = i - c * row_bytes;
-                dst[i] = (uint8_t)((stage[(c / R) * BW + (p >> 5)] >> (p & 31)) & 1u);
+                dst[i] = (uint8_t)((stage[(c / R) * RW + (p >> 5)] >> (p & 31)) & 1u);
             }
         }
     }
@@ -748,7 +756,7 @@ static bool fused_plan(int n_filters, int launch_flags, FusedPlan *p)
     // two chains per lane above 64 filters (fewest CU-cycles per clip), unless the caller asks for the low-latency
     // layout: one chain per lane = twice the waves, each half as long (1.47 against 2.43 ms for 256 clips x 128
     // filters on an idle GPU, for 12 % more CU time)
-    int nch = (n_filters > 64 && !(launch_flags & 1)) ? 2 : 1;
+    int nch = (n_filters > 64 && !(launch_flags & 1)) ? 2 : 1;       // (bit 1 of the flags concerns the LDS reservation only)
 #if LSM_EXPERIMENT_HOOKS
     static const int nch_env = [] { const char *e = getenv("LSM_GTF_NCH"); return e ? atoi(e) : 0; }();
     if (nch_env == 1 || nch_env == 2) nch = nch_env;
@@ -780,7 +788,7 @@ LSM_API int lsm_gammatone_spikes_f64(const float *audio, int n_clips, int n_samp
                                      int redundancy, uint8_t *raster, void *workspace, long workspace_bytes,
                                      int coef_flags, int launch_flags, void *stream)
 {
-    LSM_REQUIRE((launch_flags & ~1) == 0, "launch_flags: only bit 0 (low-latency layout) is defined");
+    LSM_REQUIRE((launch_flags & ~3) == 0, "launch_flags: only bit 0 (low-latency layout) and bit 1 (no LDS reservation) are defined");
     LSM_REQUIRE(n_clips >= 0 && n_filters >= 1 && n_samples >= 1, "bad shape");
     LSM_REQUIRE(nwin >= 1 && hop >= 1 && ncols >= 2 && time_bins >= 2, "bad window");
     LSM_REQUIRE(nwin <= NWIN_MAX * hop, "nwin=%d needs more than %d overlapping windows of hop=%d",
@@ -823,8 +831,9 @@ LSM_API int lsm_gammatone_spikes_f64(const float *audio, int n_clips, int n_samp
     const long n_wgs = (n_waves + pl.wpb - 1) / pl.wpb;
     LSM_REQUIRE(n_wgs <= 0x7fffffffL, "too many clips for one launch");
     // per lane row: the comparison fields of pass A (4 bins per word up to 4 thresholds, else 2), reused for the raster bits
-    const int BW = n_thr <= 4 ? (time_bins + 3) / 4 : (time_bins + 1) / 2;
-    long lds = 2 * GT_MAX_WPB * (long)sizeof(double) + (long)pl.wpb * pl.nch * 64 * BW * 4;
+    // per lane row: the raster bits of the channel (time_bins * n_thr bits), staged for the coalesced write-out
+    const int RW = (time_bins * n_thr + 31) / 32;
+    long lds = 2 * GT_MAX_WPB * (long)sizeof(double) + (long)pl.wpb * pl.nch * 64 * RW * 4;
     LSM_REQUIRE(lds <= 160 * 1024, "raster stage of %ld bytes exceeds one CU's LDS", lds);
     // CU-exclusive placement of small launches, as in lsm_gammatone_spec_f64
     {
@@ -834,7 +843,10 @@ LSM_API int lsm_gammatone_spikes_f64(const float *audio, int n_clips, int n_samp
         static const long lds_env = [] { const char *e = getenv("LSM_GTF_LDS"); return e ? atol(e) : -1L; }();
         if (lds_env >= 0) resv = lds_env;
 #endif
-        if (di.cus > 0 && n_wgs <= di.cus && di.lds_per_cu >= 4096 && resv > lds && resv <= di.lds_per_cu)
+        // launch_flags bit 1: the caller runs LDS-hungry workgroups of another kernel beside this launch (the ring-row
+        // reservoir kernel: 64-74 KB per clip, two per CU) -- no reservation then: the launch asks for what it uses
+        // (27 KB per 4-wave workgroup at 4 thresholds x 100 bins) and fits beside such a pair
+        if (!(launch_flags & 2) && di.cus > 0 && n_wgs <= di.cus && di.lds_per_cu >= 4096 && resv > lds && resv <= di.lds_per_cu)
             lds = resv;
     }
     const dim3 grid((unsigned)n_wgs), block((unsigned)(64 * pl.wpb));

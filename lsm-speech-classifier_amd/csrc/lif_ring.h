@@ -162,8 +162,9 @@ void lif_ring_kernel(const RingArgs a)
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     float *acc = reinterpret_cast<float *>(smem);                                     // dump + NPAD accumulators
-    uint32_t *cnt = reinterpret_cast<uint32_t *>(acc + RING_DUMP_WORDS + NPAD);       // dump + NPAD/2 input counts
-    uint16_t *wlist = reinterpret_cast<uint16_t *>(cnt + RING_DUMP_WORDS + NPAD / 2); // 2*NPAD: 256 per quad
+    uint32_t *cnt = reinterpret_cast<uint32_t *>(acc + RING_DUMP_WORDS + NPAD);       // dump + NPAD/2 input counts (none with INMASK)
+    constexpr int CNT_WORDS = INMASK ? 0 : RING_DUMP_WORDS + NPAD / 2;
+    uint16_t *wlist = reinterpret_cast<uint16_t *>(cnt + CNT_WORDS);                  // 2*NPAD: 256 per quad
     uint32_t *wcnt = reinterpret_cast<uint32_t *>(wlist + 2 * NPAD);                  // 2*32 quad counts + 2 stats
     uint4 *feat = reinterpret_cast<uint4 *>(wcnt + 128);                              // n_out
     uint32_t *bits = reinterpret_cast<uint32_t *>(feat + a.n_out);                    // T*CW
@@ -177,7 +178,7 @@ void lif_ring_kernel(const RingArgs a)
 #define LSM_RING_GQ(q) (STRIDED ? (q) * WPC + w : w * QL + (q))
 
     // ---- prologue: zero LDS state, bit-pack the clip's raster time-major ----
-    for (int i = tid; i < 2 * RING_DUMP_WORDS + NPAD + NPAD / 2; i += NT) reinterpret_cast<uint32_t *>(smem)[i] = 0u;
+    for (int i = tid; i < RING_DUMP_WORDS + NPAD + CNT_WORDS; i += NT) reinterpret_cast<uint32_t *>(smem)[i] = 0u;
     for (int i = tid; i < 128; i += NT) wcnt[i] = 0u;
     for (int i = tid; i < a.n_out; i += NT) feat[i] = make_uint4(0, 0, 0, 0);
     for (int i = tid; i < T * CW; i += NT) bits[i] = 0u;

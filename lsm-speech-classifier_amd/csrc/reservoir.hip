@@ -626,9 +626,10 @@ static size_t ring_lds_bytes(const lsm_reservoir *h, const RingVariant &v, int T
 {
     const size_t npad = (size_t)v.ql * 256 * v.wpc;
     const size_t cw = (size_t)(h->C + 31) / 32;
-    // float32 accumulators + 16-bit input counts (each behind 64 dump words), two step lists, quad counts,
-    // feature accumulators, the clip's input bits
-    return ((size_t)2 * lsm_lif::RING_DUMP_WORDS + npad + npad / 2) * 4 +
+    // float32 accumulators + 16-bit input counts (each behind 64 dump words; no counts when the kernel counts from
+    // per-neuron masks, INMASK), two step lists, quad counts, feature accumulators, the clip's input bits
+    const size_t cnt_words = v.inmask ? 0 : (size_t)lsm_lif::RING_DUMP_WORDS + npad / 2;
+    return ((size_t)lsm_lif::RING_DUMP_WORDS + npad + cnt_words) * 4 +
            2 * npad * 2 + 512 + (size_t)h->n_out * 16 + (size_t)T * cw * 4;
 }
 

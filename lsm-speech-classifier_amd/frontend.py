@@ -239,13 +239,17 @@ class SpikeFrontEnd:
         return raster, norm
 
     def encode(self, audio, fused: bool | None = None, low_latency: bool = False,
-               raster_out: torch.Tensor | None = None, workspace: torch.Tensor | None = None) -> torch.Tensor:
+               raster_out: torch.Tensor | None = None, workspace: torch.Tensor | None = None,
+               share_lds: bool = False) -> torch.Tensor:
         """audio (B, n_samples) -> uint8 spike raster (B, C, n_steps) on the device.  The gammatone branch is one
         launch (`lsm_gammatone_spikes_f64`); `fused=False` takes the split entry points (identical rasters), which is
         also what the mel branch takes by default (its one-launch route, `fused=True` -> `lsm_mel_spikes_f32`, measured
         slower) and what filterbanks too wide for the one-launch kernels use (`will_fuse()`).  `low_latency`: the
         fused launch in its one-chain layout (twice the waves, each half as long) -- for a batch that meets an idle
-        GPU; `pipeline.HotPath` asks for it when none of its front ends is in flight.  `raster_out` / `workspace`
+        GPU; `pipeline.HotPath` asks for it when none of its front ends is in flight.  `share_lds`: the launch runs
+        beside LDS-hungry workgroups of another kernel (the ring-row reservoir kernel, two 64 KB clips per CU): it then
+        asks for the 27 KB of LDS it uses instead of reserving half a CU's (the reservation is a placement tool for small
+        launches, `lsm_gammatone_spikes_f64` flag bit 1).  `raster_out` / `workspace`
         (fused launch only): caller-owned uint8 (B, C, n_steps) output and scratch from `new_workspace(B)` (gammatone:
         float64, at least `workspace_elems(B)` elements; mel: zero-initialised bytes), so that a steady stream of
         batches makes no allocator call at all."""
@@ -289,7 +293,7 @@ class SpikeFrontEnd:
             _lib.check(self.lib.lsm_gammatone_spikes_f64(
                 _dev(audio), B, self.n_samples, _dev(self.coefs), self.n_filters, self.nwin, self.hop,
                 self.ncols, self.time_bins, _host(on), _host(off), len(on), self.redundancy, _dev(raster),
-                _dev(ws), ws_bytes, self.coef_flags, 1 if low_latency else 0, self._stream()),
+                _dev(ws), ws_bytes, self.coef_flags, (1 if low_latency else 0) | (2 if share_lds else 0), self._stream()),
                 "lsm_gammatone_spikes_f64")
         return raster
 
