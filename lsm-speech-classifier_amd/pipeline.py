@@ -83,10 +83,6 @@ class HotPath:
         # after a synchronisation, or a caller that submits rarely) is launched in the low-latency layout: it is done
         # after 1.47 instead of 2.43 ms, and -- what matters for a short burst of steps -- the burst's front ends no
         # longer run in lockstep rounds of four that all end, and all release their reservoir launches, together.
-        # A reservoir kernel with a large per-clip LDS image (ring rows: 64-74 KB, two clips per CU) is displaced by a
-        # front-end workgroup that reserves half a CU's LDS: such pipelines launch the front end without the reservation
-        # (decided per batch size in _share_lds; LSM_FE_SHARE_LDS=0/1 forces it for A/B runs)
-        self._share = {}
         self.wide_when_idle = os.environ.get("LSM_FE_WIDE_WHEN_IDLE", "1") != "0"
         self.tail_lone_layout = os.environ.get("LSM_TAIL_LONE_LAYOUT", "1") != "0"   # diagnostic: tail steps' reservoir layout
         self._wide_below = int(os.environ.get("LSM_FE_WIDE_BELOW", "1"))     # diagnostic: front ends in flight below which the wide layout goes out
@@ -233,21 +229,12 @@ class HotPath:
             return self._one(x, stats_out, out, stage, tail), st
 
     def _share_lds(self, n_clips: int) -> bool:
-        """Whether the fused front end should give up its LDS reservation for batches of `n_clips`: the reservoir launch
-        of such a batch holds more than 40 KB of LDS per clip (the dense-row kernel at N = 1000 holds 21.5 KB and gains
-        from the reservation's one-workgroup-per-CU placement; the ring-row kernel holds 64-145 KB)."""
-        v = self._share.get(n_clips)
-        if v is None:
-            env = os.environ.get("LSM_FE_SHARE_LDS")
-            if env in ("0", "1"):
-                v = env == "1"
-            else:
-                try:
-                    v = self.net.plan(n_clips, self.fe.n_steps, self.waves_per_clip)["lds_bytes"] > 40 * 1024
-                except Exception:
-                    v = False
-            self._share[n_clips] = v
-        return v
+        """Whether the fused front end gives up its LDS reservation (`encode(share_lds=True)`).  Measured and NOT taken by
+        default: beside the ring-row kernel at 4000 neurons (64 KB per clip, two per CU; the front end needs 27 KB per
+        workgroup since round 4) the whole path runs 6.37-6.40 ms per step without the reservation against 6.26-6.28 with
+        it -- without it the dispatcher stacks several front-end workgroups on one CU
+        (profiles/r04_cfg4_frontend_lds_placement.txt).  LSM_FE_SHARE_LDS=1 switches it on for A/B runs."""
+        return os.environ.get("LSM_FE_SHARE_LDS") == "1"
 
     def _to_device(self, audio, slot):
         if isinstance(audio, np.ndarray):

@@ -134,7 +134,9 @@ def test_fused_argument_errors(torch_cuda):
     assert call() == 0
     want = raster.clone()
     assert call(flags=1) == 0 and torch_cuda.equal(raster, want)      # the low-latency layout: same raster
-    assert call(flags=2) == -1
+    assert call(flags=2) == 0 and torch_cuda.equal(raster, want)      # no LDS reservation: same raster
+    assert call(flags=3) == 0 and torch_cuda.equal(raster, want)
+    assert call(flags=4) == -1
     assert call(B=0) == 0
     assert call(ws_bytes=need - 8) == -1 and b"workspace" in lib.lsm_last_error()
     assert call(n_thr=9) == -1
