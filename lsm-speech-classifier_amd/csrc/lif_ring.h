@@ -58,6 +58,9 @@ namespace lsm_lif {
 #define LSM_RING_MARK(k)
 #endif
 
+#ifndef LSM_RING_PRIO
+#define LSM_RING_PRIO 1         // wave priority of the step loop (s_setprio 0..3; profiles/r04_ring_priority.txt)
+#endif
 #ifndef LSM_RING_DRIVE_AT
 #define LSM_RING_DRIVE_AT 0     // 0 = at the top of the step (product: 6.09 ms at cfg4), 1 = behind the first row loads of the step
 #endif                          // (6.13 ms and seven spilled registers: profiles/r04_ring_input_drive.txt)
@@ -315,6 +318,10 @@ void lif_ring_kernel(const RingArgs a)
 #if LSM_RING_PHASES
     last_ = __builtin_amdgcn_s_memtime();
 #endif
+    // Inside the pipeline the ring kernel is the stage that bounds the step (cfg4: 5.1 ms of reservoir against 2.5 ms of front
+    // end per 1024 clips), and a float64 filterbank wave shares every SIMD with its waves for 40 % of the time: the step loop runs
+    // at raised wave priority so that its latency chain is not stretched by the front end's issue slots.
+    if (LSM_RING_PRIO) __builtin_amdgcn_s_setprio(LSM_RING_PRIO);
     for (int t = 0; t < T; ++t) {
         const int cur = t & 1, prv = cur ^ 1;
         const uint16_t *list_prev = wlist + prv * NPAD;
@@ -614,6 +621,7 @@ void lif_ring_kernel(const RingArgs a)
         LSM_RING_MARK(6)               // barrier
     }
 #undef LSM_RING_GQ
+    if (LSM_RING_PRIO) __builtin_amdgcn_s_setprio(0);
 
     // ---- epilogue: health statistics, then SPEC.md §4 features from the integer accumulators ----
     if (a.stats) {
