@@ -43,6 +43,34 @@ def test_hotpath_rows_equal_the_serial_path_and_the_oracle(oracle_c):
     np.testing.assert_array_equal(host, serial.cpu().numpy())
 
 
+def test_run_gives_the_last_batches_of_a_finite_list_the_low_latency_layouts():
+    """Round 4: HotPath.run() submits the last TAIL_STEPS batches with tail=True -- front end in the one-chain layout, the
+    reservoir launch laid out as a lone launch -- so that the chip drains evenly at the end of a burst (bench.py does the
+    same for its last timed steps).  Layout hints only: the rows are those of the serial path."""
+    import torch
+    from lsm_speech_classifier_amd import frontend, pipeline, reservoir as R, snn, synth
+    audio = synth.class_chirps(np.arange(6 * 32) % 12, seed=5)
+    fe = frontend.SpikeFrontEnd(128, "gammatone")
+    net = snn.SNN(R.SimulationParams(num_neurons=1000, num_output_neurons=400, small_world_graph_k=200, mean_weight=0.006),
+                  n_channels=128)
+    serial, _, _ = net.run_batch(fe.encode(audio), KEYS)
+    batches = [torch.from_numpy(audio[lo:lo + 32]).cuda() for lo in range(0, len(audio), 32)]
+    hp = pipeline.HotPath(fe, net, KEYS)
+    seen_fe, seen_wpc = [], []
+    real_encode, real_run = fe.encode, net.run_batch
+    fe.encode = lambda x, **kw: (seen_fe.append(bool(kw.get("low_latency"))), real_encode(x, **kw))[1]
+    net.run_batch = lambda r, keys=None, **kw: (seen_wpc.append(kw.get("waves_per_clip")), real_run(r, keys, **kw))[1]
+    try:
+        got = hp.run(batches)
+    finally:
+        fe.encode, net.run_batch = real_encode, real_run
+    assert torch.equal(got, serial)
+    n = pipeline.TAIL_STEPS
+    assert n >= 1 and seen_fe[-n:] == [True] * n and seen_wpc[-n:] == [0] * n      # the tail
+    assert seen_fe[0] is True and seen_wpc[0] == -1                                # first step: idle GPU, pipeline layout
+    assert seen_fe[1:-n].count(True) <= 1 and set(seen_wpc[:-n]) == {-1}
+
+
 def test_in_memory_route_writes_the_same_file_2(tmp_path, monkeypatch):
     import create_dataset as cd
     import extract_lsm_features as ex
