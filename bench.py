@@ -330,6 +330,7 @@ def run_rank(args):
     gathered = (torch.empty((world * args.steps * B, n_feat), dtype=torch.float32, device=dev)
                 if local_rows is not None else None)
 
+    collective_host_ms = []             # host time of every chunk's enqueue (waits + collective call): must stay microseconds
     done_events = []                    # one event per step of the current phase (warm-up or timed), behind its last launch
 
     def gather_chunk(c0, c1):
@@ -339,10 +340,12 @@ def run_rank(args):
     def gather_behind(c0, c1):
         """The chunk's all-gather on the exchange stream, ordered behind the chunk's steps (GPU-side waits only).
         RCCL orders its own stream behind `xs`; no pipeline stream ever waits for a gather."""
+        h0 = time.perf_counter()
         with torch.cuda.stream(xs):
             for ev in done_events[c0:c1]:
                 xs.wait_event(ev)
             gather_chunk(c0, c1)
+        collective_host_ms.append((time.perf_counter() - h0) * 1e3)
 
     def step(i, n_exchanged=0, tail=False):
         """One pass of the hot path over the batch on the next stream of the rotation (HotPath.submit, also for
@@ -384,14 +387,33 @@ def run_rank(args):
         end.record(cur)
         return end
 
+    DIAG_IDLE_MS = float(os.environ.get("LSM_BENCH_DIAG_IDLE_MS", "0"))
+
     def fence():
-        torch.cuda.synchronize()
+        """The bracket of the timed region: barrier + torch.cuda.synchronize().  With several ranks the barrier (RCCL: a
+        one-element all-reduce the host waits for) is enqueued BEHIND this rank's GPU work -- the current stream first waits
+        for every stream of the pipeline, GPU-side -- so the host waits once, for "my work is done and every rank got
+        here", and the synchronisation that follows finds an idle GPU; the other order (synchronize, barrier,
+        synchronize) costs two more host round trips, each of them idle GPU time (inside the timed region at its end, in
+        front of it at its start, where the clock governor sees it: profiles/r04_one_rank_rccl_fences.txt).
+        Returns the host time of the two calls (ms)."""
+        f0 = time.perf_counter()
         if use_dist:
+            hp.join_to_current()
+            if xs is not None:
+                torch.cuda.current_stream(dev).wait_stream(xs)
             dist.barrier()
-            torch.cuda.synchronize()
+        f1 = time.perf_counter()
+        torch.cuda.synchronize()
+        return (f1 - f0) * 1e3, (time.perf_counter() - f1) * 1e3
 
     def timed_pass(prime_ms):
         """Set-up (prime), W untimed warm-up steps, then EXACTLY K timed steps between two fences."""
+        if use_dist:
+            # RCCL sets up its all-reduce on the FIRST barrier (5-16 ms on one rank, profiles/r04_one_rank_rccl_fences.txt):
+            # paid here, or the fence in front of the timed region leaves the GPU idle for that long and the region starts
+            # at the clock of an idle chip (3 ms of idleness cost the 20-step burst 6 %, same file)
+            dist.barrier()
         primed = hp.prime(stage_in, stage=args.stage, min_ms=prime_ms)
         hp.fork_from_current()             # inputs were produced on the default stream
         n_w = min(args.warmup, args.steps)
@@ -399,16 +421,19 @@ def run_rank(args):
         for i in range(args.warmup):
             step(i, n_w)
         finish_exchange(n_w)               # RCCL's own one-off set-up belongs to the warm-up too
-        fence()
+        start_fence = fence()
+        if DIAG_IDLE_MS > 0:               # diagnostic: an idle GPU for this long right before the timed region
+            time.sleep(DIAG_IDLE_MS / 1e3)
         hp.reservoir_events.clear()
         done_events.clear()
+        collective_host_ms.clear()
         t0 = time.perf_counter()
         out = None
         for i in range(args.steps):
             out = step(i, args.steps, tail=i >= args.steps - tail_steps)   # what HotPath.run() does for a finite list
         enqueue_ms = (time.perf_counter() - t0) / args.steps * 1e3      # host side of a step (asynchronous)
         x_end = finish_exchange(args.steps)                              # inside the timed region, before the fence
-        fence()
+        end_fence = fence()
         elapsed = time.perf_counter() - t0
         if use_dist:
             t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
@@ -420,7 +445,9 @@ def run_rank(args):
         if x_end is not None and done_events:
             exposed = max(0.0, min(ev.elapsed_time(x_end) for ev in done_events))
         return {"elapsed": elapsed, "enqueue_ms": enqueue_ms, "primed": primed, "out": out, "exchange_ms": exposed,
-                "ev_pairs": list(hp.reservoir_events)}
+                "ev_pairs": list(hp.reservoir_events),
+                "fences": {"start_barrier_ms": round(start_fence[0], 4), "start_synchronize_ms": round(start_fence[1], 4),
+                           "end_barrier_ms": round(end_fence[0], 4), "end_synchronize_ms": round(end_fence[1], 4)}}
 
     # the 40 ms of HotPath.prime() are a measurement-protocol choice (the clock governor at its working
     # point, profiles/r03_clock_ramp.txt).  The first pass keeps round 2's protocol -- one step per stream, W warm-up
@@ -524,12 +551,19 @@ def run_rank(args):
         }
         if unprimed is not None:
             line["unprimed"] = unprimed
+        # host clock, this rank: the two calls of the fences that bracket the timed region (the barrier, enqueued behind
+        # this rank's GPU work, waits for that work AND the other ranks; 0 without a process group).  end_* lie INSIDE the
+        # timed region
+        line["fences"] = res_pass["fences"]
+        if DIAG_IDLE_MS > 0:
+            line["fences"]["diag_idle_ms_before_region"] = DIAG_IDLE_MS
         if use_dist and once and args.stage != "frontend":
             line["exchange"] = {
                 "mode": args.exchange, "chunk_steps": chunk if xs is not None else args.steps,
                 "exchange_ms": None if exchange_ms is None else round(exchange_ms, 4),
                 "exchange_bytes": world * args.steps * B * n_feat * 4,
                 "bytes_sent_per_rank": args.steps * B * n_feat * 4, "digest": exchange_digest,
+                "host_enqueue_ms_per_collective": [round(x, 4) for x in collective_host_ms] or None,
                 "note": "exchange_ms = exposed tail: from the moment the last step's kernels finished to the end of the "
                         "exchange (HIP events, max over ranks), inside the timed region; exchange_bytes = what every "
                         "rank holds afterwards"}

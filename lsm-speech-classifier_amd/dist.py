@@ -146,10 +146,10 @@ def gather_step_chunk(gathered: torch.Tensor, local_rows: torch.Tensor, c0: int,
     B, F = local_rows.shape[1], local_rows.shape[2]
     src = local_rows[c0:c1].reshape((c1 - c0) * B, F)
     dst = gathered[world * c0 * B: world * c1 * B]
-    if world == 1:
-        dst.copy_(src)
-    else:
+    if dist.is_initialized():            # also with one rank: the rehearsal on a 1-GPU box goes through RCCL's call path
         dist.all_gather_into_tensor(dst, src)
+    else:
+        dst.copy_(src)
 
 
 def rows_by_rank(gathered: torch.Tensor, world: int, n_steps: int, chunk: int, rows_per_step: int):
