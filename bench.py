@@ -367,7 +367,7 @@ def run_rank(args):
                 gather_behind(i + 1 - chunk, i + 1)      # this chunk's rows travel while the next steps run
         return feats
 
-    def finish_exchange(n_steps):
+    def finish_exchange(n_steps, rehearsal=False):
         """What is still due of the exchange after the last step, inside the timed region: 'once' = the one all-gather
         behind every stream of the pipeline (no host wait); 'chunked' = the tail chunk (when the chunk size does not
         divide the steps) and the edge that makes the current stream wait for the exchange stream.  Returns an
@@ -377,7 +377,9 @@ def run_rank(args):
         cur = torch.cuda.current_stream(dev)
         if xs is None:
             hp.join_to_current()
-            gather_chunk(0, n_steps)
+            # the warm-up's gather has the size of the timed one (RCCL picks protocol and buffers by message size; whatever
+            # it sets up on first use of a size must not happen inside the timed region)
+            gather_chunk(0, args.steps if rehearsal else n_steps)
         else:
             sent = (n_steps // chunk) * chunk
             if sent < n_steps:
@@ -420,7 +422,7 @@ def run_rank(args):
         done_events.clear()
         for i in range(args.warmup):
             step(i, n_w)
-        finish_exchange(n_w)               # RCCL's own one-off set-up belongs to the warm-up too
+        finish_exchange(n_w, rehearsal=True)    # RCCL's own one-off set-up belongs to the warm-up too
         start_fence = fence()
         if DIAG_IDLE_MS > 0:               # diagnostic: an idle GPU for this long right before the timed region
             time.sleep(DIAG_IDLE_MS / 1e3)
