@@ -201,6 +201,13 @@ def test_bench_rccl_code_path_with_one_rank():
     # the default exchange on RCCL: chunks of 5 steps on the exchange stream + the tail chunk, 16 hardware queues
     assert d["exchange"]["mode"] == "chunked" and d["exchange"]["chunk_steps"] == 5 and d["config"]["hw_queues"] == 16
     assert 0.0 <= d["exchange"]["exchange_ms"] < 5.0 and d["exchange"]["digest"] != 0
+    # enqueueing a chunk's collective never waits for the GPU (the pipeline must keep running under it)
+    assert all(ms < 2.0 for ms in d["exchange"]["host_enqueue_ms_per_collective"])
+    # RCCL's first barrier (its one-off set-up: 5-16 ms of idle GPU) was paid before the warm-up, not in the fence in
+    # front of the timed region: that fence only waits for the two warm-up steps (profiles/r04_one_rank_rccl_fences.txt)
+    f = d["fences"]
+    assert f["start_barrier_ms"] + f["start_synchronize_ms"] < 6.0
+    assert f["end_barrier_ms"] + f["end_synchronize_ms"] <= d["ms_per_step"] * d["steps"] * 1.001
 
 
 @pytest.mark.parametrize("world,n", [(2, 9), (3, 2)])          # uneven shards; 3 ranks for 2 clips: an empty shard
