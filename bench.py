@@ -384,6 +384,15 @@ def run_rank(args):
             sent = (n_steps // chunk) * chunk
             if sent < n_steps:
                 gather_behind(sent, n_steps)
+            if rehearsal:
+                # every chunk size the timed region will use has been gathered once before it starts (a warm-up shorter
+                # than a chunk, or a tail chunk of another size, would otherwise meet RCCL's first use of that size there)
+                sizes = {min(chunk, args.steps), args.steps % chunk} - {0}
+                seen = {chunk} if n_steps >= chunk else set()
+                seen.add(n_steps - sent)
+                with torch.cuda.stream(xs):
+                    for k in sorted(sizes - seen):
+                        gather_chunk(0, k)
             cur.wait_stream(xs)
         end = torch.cuda.Event(enable_timing=True)
         end.record(cur)
