@@ -680,7 +680,9 @@ def run_rank(args):
                     "note": "peak = one float64 operation per lane and instruction on all 1024 SIMDs with >= 4 waves "
                             "each (78.6 TFLOPS counts an FMA as two); idle_gpu = ONE launch alone (the one-launch front end "
                             "occupies a quarter of the chip at 128 filters / 256 clips: four in flight cover it), pipeline = "
-                            "the same instruction count over the measured step time of the whole overlapped path",
+                            "the same instruction count over the measured step time of the whole overlapped path; at cfg2 "
+                            "the overlapped path runs at the socket's power limit (1380-1390 of 1400 W, shader clock throttled "
+                            "to 2.29-2.33 GHz: profiles/r04_clock_power_under_load.txt, not measured in this run)",
                 }
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(cfg, audio_np, res)
