@@ -367,7 +367,7 @@ def run_rank(args):
                 gather_behind(i + 1 - chunk, i + 1)      # this chunk's rows travel while the next steps run
         return feats
 
-    def finish_exchange(n_steps, rehearsal=False):
+    def finish_exchange(n_steps):
         """What is still due of the exchange after the last step, inside the timed region: 'once' = the one all-gather
         behind every stream of the pipeline (no host wait); 'chunked' = the tail chunk (when the chunk size does not
         divide the steps) and the edge that makes the current stream wait for the exchange stream.  Returns an
@@ -377,22 +377,11 @@ def run_rank(args):
         cur = torch.cuda.current_stream(dev)
         if xs is None:
             hp.join_to_current()
-            # the warm-up's gather has the size of the timed one (RCCL picks protocol and buffers by message size; whatever
-            # it sets up on first use of a size must not happen inside the timed region)
-            gather_chunk(0, args.steps if rehearsal else n_steps)
+            gather_chunk(0, n_steps)
         else:
             sent = (n_steps // chunk) * chunk
             if sent < n_steps:
                 gather_behind(sent, n_steps)
-            if rehearsal:
-                # every chunk size the timed region will use has been gathered once before it starts (a warm-up shorter
-                # than a chunk, or a tail chunk of another size, would otherwise meet RCCL's first use of that size there)
-                sizes = {min(chunk, args.steps), args.steps % chunk} - {0}
-                seen = {chunk} if n_steps >= chunk else set()
-                seen.add(n_steps - sent)
-                with torch.cuda.stream(xs):
-                    for k in sorted(sizes - seen):
-                        gather_chunk(0, k)
             cur.wait_stream(xs)
         end = torch.cuda.Event(enable_timing=True)
         end.record(cur)
@@ -418,20 +407,36 @@ def run_rank(args):
         torch.cuda.synchronize()
         return (f1 - f0) * 1e3, (time.perf_counter() - f1) * 1e3
 
+    def rehearse_collectives():
+        """RCCL sets itself up on FIRST use -- of the barrier's all-reduce (5-16 ms on one rank), of an all-gather, perhaps of
+        every message size (protocol, buffers).  All of it happens here, before the pipeline is primed: a first use during
+        the warm-up steps blocks the host for milliseconds while the GPU runs out of queued work, and the fence then
+        finds a GPU that has been idle for that long -- the timed region starts at an idle chip's clock (traced:
+        profiles/r04_one_rank_rccl_fences.txt, 3 ms of idleness cost the 20-step burst 6 %)."""
+        if not use_dist:
+            return
+        dist.barrier()
+        if gathered is not None:
+            sizes = ({min(chunk, args.steps), args.steps % chunk, min(args.warmup, args.steps) % chunk} - {0}
+                     if xs is not None else {args.steps, min(args.warmup, args.steps)} - {0})
+            st = xs if xs is not None else torch.cuda.current_stream(dev)
+            with torch.cuda.stream(st):
+                for k in sorted(sizes):
+                    gather_chunk(0, k)
+        if gather_bufs is not None:
+            dist.all_gather_into_tensor(gather_bufs[0], torch.empty((B, n_feat), dtype=torch.float32, device=dev))
+        torch.cuda.synchronize()
+
     def timed_pass(prime_ms):
         """Set-up (prime), W untimed warm-up steps, then EXACTLY K timed steps between two fences."""
-        if use_dist:
-            # RCCL sets up its all-reduce on the FIRST barrier (5-16 ms on one rank, profiles/r04_one_rank_rccl_fences.txt):
-            # paid here, or the fence in front of the timed region leaves the GPU idle for that long and the region starts
-            # at the clock of an idle chip (3 ms of idleness cost the 20-step burst 6 %, same file)
-            dist.barrier()
+        rehearse_collectives()
         primed = hp.prime(stage_in, stage=args.stage, min_ms=prime_ms)
         hp.fork_from_current()             # inputs were produced on the default stream
         n_w = min(args.warmup, args.steps)
         done_events.clear()
         for i in range(args.warmup):
             step(i, n_w)
-        finish_exchange(n_w, rehearsal=True)    # RCCL's own one-off set-up belongs to the warm-up too
+        finish_exchange(n_w)
         start_fence = fence()
         if DIAG_IDLE_MS > 0:               # diagnostic: an idle GPU for this long right before the timed region
             time.sleep(DIAG_IDLE_MS / 1e3)

@@ -13,7 +13,7 @@ print('$1', '->', d['value'], 'clips/s', d['ms_per_step'], 'ms/step; fences', d.
 D="RANK=0 LOCAL_RANK=0 WORLD_SIZE=1 MASTER_ADDR=127.0.0.1 MASTER_PORT=29533 LSM_BENCH_FORCE_DIST=1"
 for rep in 1 2 3; do
   python3 bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline --no-unprimed 2>/dev/null | line "plain" >> $O/x.txt
-  for M in once chunked; do
+  for M in once chunked per-step; do
     env $D python3 bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline --exchange $M 2>/dev/null | line "one RCCL rank, $M" >> $O/x.txt
   done
 done
