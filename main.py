@@ -68,6 +68,7 @@ def _launch(script_args, nproc: int):
     """One process, or `nproc` ranks of it (one per GPU) through torch.distributed.run."""
     if nproc <= 1:
         return [sys.executable] + script_args
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # inherited by the ranks: dmabuf IPC, which RCCL needs here
     return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={nproc}",
             "--master-addr", "127.0.0.1", "--master-port", os.environ.get("LSM_MASTER_PORT", "29517")] + script_args
 
