@@ -73,7 +73,7 @@ def parse_args(argv=None):
     ap.add_argument("--batch", type=int, default=0, help="clips per GPU (0 = the config's)")
     ap.add_argument("--waves-per-clip", type=int, default=None,
                     help="reservoir layout (default: the library chooses, knowing whether steps overlap)")
-    ap.add_argument("--kernel", default="auto", choices=["auto", "dense", "ring", "sparse"])
+    ap.add_argument("--kernel", default="auto", choices=["auto", "dense", "ring", "ring-pairs", "ring-quads", "sparse"])
     ap.add_argument("--stage", default="full", choices=["full", "reservoir", "frontend"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--from-host", action="store_true",

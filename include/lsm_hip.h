@@ -33,7 +33,11 @@ extern "C" {
 #define LSM_ERR_NOMEM (-3)
 #define LSM_ERR_UNSUPPORTED (-4)
 
-int lsm_version(void);                 /* major*10000 + minor*100 + patch */
+int lsm_version(void);                 /* major*10000 + minor*100 + patch of the package version the library was built as */
+/* "LSM_BUILD_ID=<24 hex digits>": hash of every source and header of csrc/, this header, the compiler flags and the
+ * version, linked in by lsm-speech-classifier_amd/build.py.  The Python loader refuses a library whose id is not the one
+ * of the tree it sits in (a stale binary cannot pass for a build of the sources beside it). */
+const char *lsm_build_id(void);
 const char *lsm_last_error(void);
 int lsm_device_count(void);
 

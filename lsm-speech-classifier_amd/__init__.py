@@ -32,4 +32,4 @@ def _configure_hw_queues(default: int = 12) -> int:
 
 EFFECTIVE_HW_QUEUES = _configure_hw_queues()
 
-__version__ = "0.4.0"
+__version__ = "0.5.0"

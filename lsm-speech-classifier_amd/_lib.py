@@ -8,7 +8,7 @@ import os
 from . import build as _build
 
 _lib = None
-ABI_VERSION = 400          # lsm_version() of the library this binding was written against (0.4.0 = __version__)
+ABI_VERSION = _build.version_number()      # lsm_version() of a library built from this tree (= __version__, one literal)
 
 c_void = C.c_void_p
 c_int = C.c_int
@@ -16,6 +16,7 @@ c_float = C.c_float
 
 _SIGS = {
     "lsm_version": (c_int, []),
+    "lsm_build_id": (C.c_char_p, []),
     "lsm_last_error": (C.c_char_p, []),
     "lsm_device_count": (c_int, []),
     "lsm_gammatone_spec_f64": (c_int, [c_void, c_int, c_int, c_void, c_int, c_int, c_int, c_int,
@@ -74,6 +75,20 @@ def load():
     # leave the second one without devices.
     import torch  # noqa: F401
     path = _build.lib_path()
+    own = "LSM_HIP_LIB" not in os.environ        # a diagnostic build named by the user is loaded as it is
+    # A library that is absent, of another version or built from other sources than this tree's (build.source_id, linked
+    # into the binary) is rebuilt ONCE -- hipcc runs as a child process, nothing here touches the GPU -- and refused if
+    # that does not help: never a silent stale binary, never a CPU fallback.
+    if own and _build.needs_build(path) and os.environ.get("LSM_NO_AUTO_BUILD") != "1":
+        try:
+            import fcntl
+            os.makedirs(os.path.join(_build.PKG_DIR, "build"), exist_ok=True)
+            with open(os.path.join(_build.PKG_DIR, "build", ".lock"), "w") as lock:
+                fcntl.flock(lock, fcntl.LOCK_EX)         # the ranks of a launcher find the same stale library together
+                _build.build()                           # (a no-op for every rank but the first)
+        except Exception as e:                   # no hipcc (a box that only received the binary): judged below
+            import warnings
+            warnings.warn(f"rebuilding {path} failed: {e}", RuntimeWarning)
     if not os.path.exists(path):
         raise LsmHipError(
             f"{path} not found: the HIP extension is not built. Run `python -c \"import "
@@ -88,6 +103,10 @@ def load():
         raise LsmHipError(
             f"{path} reports ABI version {have}, this package needs {ABI_VERSION}: rebuild the extension "
             f"(`python -c \"import __graft_entry__ as g; g.build()\"`).")
+    if own and _build.built_id(path) != _build.source_id():
+        raise LsmHipError(
+            f"{path} was built from other sources than this tree's (build id {_build.built_id(path)}, sources "
+            f"{_build.source_id()}): rebuild the extension (`python -c \"import __graft_entry__ as g; g.build()\"`).")
     for name, (res, args) in _SIGS.items():
         fn = getattr(lib, name)          # AttributeError here = header/library mismatch
         fn.restype = res

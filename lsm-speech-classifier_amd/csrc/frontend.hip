@@ -227,6 +227,7 @@ __global__ __launch_bounds__(GT_MAX_WPB * 64) void gammatone_spikes_kernel(const
     double z01[NCH], z11[NCH], z02[NCH], z12[NCH], z03[NCH], z13[NCH], z04[NCH], z14[NCH];
     double win[NCH][NW];
     double mx[NCH], mn[NCH];
+    bool nan_seen = false;                              // a NaN among my dB values (the comparisons below skip it)
 #pragma unroll
     for (int q = 0; q < NCH; ++q) {
         z01[q] = z11[q] = z02[q] = z12[q] = z03[q] = z13[q] = z04[q] = z14[q] = 0.0;
@@ -314,6 +315,7 @@ __global__ __launch_bounds__(GT_MAX_WPB * 64) void gammatone_spikes_kernel(const
                     if (live[q]) {
                         mx[q] = v > mx[q] ? v : mx[q];
                         mn[q] = v < mn[q] ? v : mn[q];
+                        nan_seen |= v != v;
                     }
                 }
             }
@@ -345,20 +347,26 @@ __global__ __launch_bounds__(GT_MAX_WPB * 64) void gammatone_spikes_kernel(const
         hi = oh > hi ? oh : hi;
         lo = ol < lo ? ol : lo;
     }
+    // spec_db.max() / .min() / np.maximum (create_dataset.py:59-63) propagate NaN: one NaN among the clip's dB values makes
+    // max, floor and min NaN -- every normalised value NaN, the raster all zeros (tests/golden/postfilter_nonfinite.npz)
+    if (__builtin_amdgcn_ballot_w64(nan_seen) != 0ull) hi = lo = (double)NAN;
     if (groups > 1) {                                   // uniform over the launch
         if (lane == 0) { xch[2 * wave] = hi; xch[2 * wave + 1] = lo; }
         __syncthreads();
         const int w0 = wave - g;                        // first wave of this clip in the workgroup
         hi = xch[2 * w0]; lo = xch[2 * w0 + 1];
+        bool nan_any = hi != hi;
         for (int i = 1; i < groups; ++i) {
             const double oh = xch[2 * (w0 + i)], ol = xch[2 * (w0 + i) + 1];
             hi = oh > hi ? oh : hi;
             lo = ol < lo ? ol : lo;
+            nan_any = nan_any || oh != oh;
         }
+        if (nan_any) hi = lo = (double)NAN;
     }
     // create_dataset.py:60 floors at max-80 before the min is taken: min' = max(min, max-80)
     const double fl = hi - 80.0;
-    lo = lo > fl ? lo : fl;
+    lo = lo > fl ? lo : fl;                             // (NaN: fl)
     const bool flat = (hi - lo) < 1e-8;
     const double den = (hi - lo) + 1e-8;
     const int Tb = a.time_bins, n_thr = a.n_thr;

@@ -1,0 +1,6 @@
+// Pair-block ring LIF kernel instantiations with 1 block(s) (= 2 neurons per lane) per wave (see lif_pair.h).
+#include "lif_pair.h"
+
+namespace lsm_lif {
+pair_fn_t pick_pair_1(int wpc, int inmask) { return pick_pair<1>(wpc, inmask); }
+}  // namespace lsm_lif

@@ -1,0 +1,6 @@
+// Pair-block ring LIF kernel instantiations with 2 block(s) (= 4 neurons per lane) per wave (see lif_pair.h).
+#include "lif_pair.h"
+
+namespace lsm_lif {
+pair_fn_t pick_pair_2(int wpc, int inmask) { return pick_pair<2>(wpc, inmask); }
+}  // namespace lsm_lif

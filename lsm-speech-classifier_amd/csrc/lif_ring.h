@@ -68,6 +68,30 @@ namespace lsm_lif {
 #ifndef LSM_RING_DRIVE_ALL_LANES
 #define LSM_RING_DRIVE_ALL_LANES 0
 #endif
+// Diagnostic builds only (results stay right): extra scalar / vector / LDS instructions per row and wave, to see which
+// issue port the row loop is bound by (profiles/r05_ring_issue_ports.txt).
+#ifndef LSM_RING_DUMMY_SALU
+#define LSM_RING_DUMMY_SALU 0
+#endif
+#ifndef LSM_RING_DUMMY_VALU
+#define LSM_RING_DUMMY_VALU 0
+#endif
+#ifndef LSM_RING_DUMMY_LDS
+#define LSM_RING_DUMMY_LDS 0
+#endif
+#if LSM_RING_DUMMY_SALU || LSM_RING_DUMMY_VALU || LSM_RING_DUMMY_LDS
+#define LSM_RING_DUMMY_WORK                                                                                     \
+    {                                                                                                           \
+        _Pragma("unroll") for (int d_ = 0; d_ < LSM_RING_DUMMY_SALU; ++d_)                                      \
+            asm volatile("s_add_u32 %0, %0, 1" : "+s"(dummy_s_) : : "scc");                                     \
+        _Pragma("unroll") for (int d_ = 0; d_ < LSM_RING_DUMMY_VALU; ++d_)                                      \
+            asm volatile("v_add_u32 %0, 1, %0" : "+v"(dummy_v_));                                               \
+        _Pragma("unroll") for (int d_ = 0; d_ < LSM_RING_DUMMY_LDS; ++d_)                                       \
+            asm volatile("ds_write_b32 %0, %1" : : "v"(lane4), "v"(dummy_v_) : "memory");  /* my dump word */   \
+    }
+#else
+#define LSM_RING_DUMMY_WORK
+#endif
 #ifndef LSM_RING_ABLATE
 #define LSM_RING_ABLATE 0   // diagnostic builds only (1, 2, 8, 16, 32 give WRONG results): 1 = no window loads, 2 = no
 #endif                      // accumulator read-modify-write, 8 = no list loads, 16 = no input drive, 32 = no feature updates;
@@ -263,6 +287,9 @@ void lif_ring_kernel(const RingArgs a)
     uint32_t rows_ = 0u;
     uint64_t last_ = 0;
 #endif
+#if LSM_RING_DUMMY_SALU || LSM_RING_DUMMY_VALU || LSM_RING_DUMMY_LDS
+    uint32_t dummy_s_ = 0u, dummy_v_ = 0u;
+#endif
     uint32_t hf = 0u;                  // bit r: my neuron r fired at least once (stats)
     uint32_t tot_spk = 0u;             // spikes of my wave (stats)
     __syncthreads();
@@ -416,6 +443,7 @@ void lif_ring_kernel(const RingArgs a)
             // exist: their num_records is 0, every load is out of range and returns zeros without traffic.
 #define LSM_RING_LOADW(p, m)                                                                    \
     {                                                                                           \
+        LSM_RING_DUMMY_WORK                                                                     \
         const int mm = (m) & 63;                                                                \
         const uint32_t live = (uint32_t) - (int)((m) < n);                                      \
         const uint32_t ra = __builtin_amdgcn_readlane(p_a, mm);                                 \

@@ -30,8 +30,15 @@ void lsm_allow_big_lds(const void *kernel_fn)
 
 #define LSM_API extern "C" __attribute__((visibility("default")))
 
-// major*10000 + minor*100 + patch; in step with the package's __version__ and _lib.ABI_VERSION (which refuses another number)
-LSM_API int lsm_version(void) { return 400; }   // 0.4.0
+// major*10000 + minor*100 + patch of the package's __version__: build.py passes it (and the identity of the sources the
+// library is built from) on this file's command line, so there is ONE place where the number is written; _lib.load()
+// refuses a library whose version or build id is not the tree's.
+#ifndef LSM_VERSION_NUMBER
+#error "build through lsm-speech-classifier_amd/build.py: it defines LSM_VERSION_NUMBER and LSM_BUILD_ID_STRING"
+#endif
+LSM_API int lsm_version(void) { return LSM_VERSION_NUMBER; }
+// "LSM_BUILD_ID=<24 hex digits>": hash of every source and header, the flags and the version (build.source_id)
+LSM_API const char *lsm_build_id(void) { return LSM_BUILD_ID_STRING; }
 
 LSM_API const char *lsm_last_error(void) { return g_err; }
 

@@ -125,11 +125,22 @@ __device__ __forceinline__ void power_to_db_body(const float *__restrict__ p, fl
                                                  float top_db, float *red)
 {
     float mx = -INFINITY;
-    for (int i = threadIdx.x; i < n; i += 256) mx = fmaxf(mx, p[i]);
+    int nan_seen = 0;
+    for (int i = threadIdx.x; i < n; i += 256) {
+        const float v = p[i];
+        mx = fmaxf(mx, v);
+        nan_seen |= v != v;
+    }
     for (int off = 32; off > 0; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off));
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = mx;
-    __syncthreads();
+    // np.max / np.maximum propagate NaN (fmaxf drops it): one NaN power value makes the reference level, and with it every
+    // dB value of the clip, NaN (librosa.power_to_db(S, ref=np.max), SPEC.md 1.5)
+    const int any_nan = __syncthreads_or(nan_seen);
     mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    if (any_nan) {
+        for (int i = threadIdx.x; i < n; i += 256) o[i] = NAN;
+        return;
+    }
     const float refdb = 10.0f * log10f(fmaxf(amin, mx));
     // the maximum of (10*log10(max(amin, S)) - refdb) is exactly 0, so the floor is -top_db
     for (int i = threadIdx.x; i < n; i += 256) {

@@ -3,6 +3,7 @@
 // is instantiated by the four lif_variant_*.hip translation units.
 #include "lif_dense.h"
 #include "lif_ring.h"
+#include "lif_pair.h"
 
 #include <algorithm>
 #include <climits>
@@ -63,6 +64,16 @@ struct RingVariant {        // per waves-per-clip layout of the ring-row kernel 
     bool incol = false;              // the masks use the coloured bit positions of lsm_reservoir::inperm
 };
 
+struct PairVariant {        // per waves-per-clip layout of the pair-block ring kernel (lif_pair.h)
+    int wpc = 0, bl = 0;             // wave w owns the 128-neuron blocks w, w+wpc, ...: bl of them
+    size_t n_rem = 0;                // list entries (synapses outside the ring window)
+    uint4 *rec = nullptr;            // (N*wpc) row records (lsm_lif::pair_record)
+    uint2 *rem = nullptr;            // {LDS byte offset of the accumulator, weight bits}, (row, wave) major
+    int *oslot = nullptr;
+    uint32_t *inmask = nullptr;      // (npad, 4) input-channel masks in neuron order
+    bool incol = false;              // the masks use the coloured bit positions of lsm_reservoir::inperm
+};
+
 }  // namespace
 
 // Dense presynaptic rows from the device copy of the CSC arrays: block j scatters column j into row j.
@@ -100,9 +111,11 @@ struct lsm_reservoir {
     bool leak_uniform = false;       // every neuron has the same leak coefficient (leak_u): the reference's default
     float leak_u = 0.0f;
     int mode = 0;           // 0 auto, 1 sparse (CSC scatter through LDS), 2 dense rows, 3 ring rows,
-                            // 4 ring rows with contiguous quad ownership only (tests)
+                            // 4 ring rows with contiguous quad ownership only (tests), 5 ring rows in pair blocks only
+                            // (lif_pair.h), 6 ring rows in quads only (lif_ring.h, either ownership)
     Variant var[5];         // wpc = 1, 2, 4, 8, 16 (wpc == 0: not available)
     RingVariant rvar[8];    // wpc = 2, 4, 8, 16, contiguous [0..3] and strided [4..7] quad ownership
+    PairVariant pvar[3];    // wpc = 4, 8, 16: pair blocks (lif_pair.h), uniform leak and C <= 128 only
 };
 
 static int free_reservoir(lsm_reservoir *h)
@@ -129,6 +142,12 @@ static int free_reservoir(lsm_reservoir *h)
         if (v.oslot) (void)hipFree(v.oslot);
         if (v.in_ent) (void)hipFree(v.in_ent);
     }
+    for (auto &v : h->pvar) {
+        if (v.rec) (void)hipFree(v.rec);
+        if (v.rem) (void)hipFree(v.rem);
+        if (v.oslot) (void)hipFree(v.oslot);
+        if (v.inmask) (void)hipFree(v.inmask);
+    }
     delete h;
     return LSM_OK;
 }
@@ -138,6 +157,12 @@ static size_t ring_lds_bytes(const lsm_reservoir *h, const RingVariant &v, int T
 static bool has_ring(const lsm_reservoir *h)
 {
     for (const auto &v : h->rvar)
+        if (v.wpc) return true;
+    return false;
+}
+static bool has_pairs(const lsm_reservoir *h)
+{
+    for (const auto &v : h->pvar)
         if (v.wpc) return true;
     return false;
 }
@@ -545,6 +570,89 @@ int lsm_reservoir_create(lsm_reservoir **out, int num_neurons, int n_channels,
                     }
                     v.wpc = wpc; v.ql = ql; v.einw = einw; v.strided = strided; v.n_rem = rptr.back();
                 }
+                // Pair blocks (lif_pair.h): the same windows shared out in 128-neuron blocks, wave w owning the blocks
+                // w, w+wpc, ...: the residues must survive the ring's wrap (2*NQ % wpc == 0), a window must not touch more
+                // than wpc blocks, a wave at most four blocks (8 neurons per lane).  The kernel counts the input drive from
+                // per-neuron channel masks only: one leak coefficient for every neuron and C <= 128.
+#if LSM_EXPERIMENT_HOOKS
+                static const bool no_pairs = [] { const char *e = getenv("LSM_RING_NO_PAIRS"); return e && atoi(e) != 0; }();
+#else
+                constexpr bool no_pairs = false;
+#endif
+                const int NB = 2 * NQ;
+                int wsb = 0;
+                for (int j = 0; j < N; ++j) wsb = std::max(wsb, (((a4v[j] & 127) + (nbytes[j] / 4 - 1)) >> 7) + 1);
+                const int pwpcs[3] = {4, 8, 16};
+                for (int vi = 0; vi < 3 && !no_pairs && C <= 128 && h->leak_uniform; ++vi) {
+                    const int wpc = pwpcs[vi];
+                    if (NB % wpc != 0 || wsb > wpc) continue;
+                    const int bl = NB / wpc;
+                    if (bl < 1 || bl > 4) continue;
+                    const int npad = NB * 128;
+                    std::vector<uint32_t> rptr((size_t)N * wpc + 1, 0u);
+                    int emax = 0;
+                    for (int j = 0; j < N; ++j)
+                        for (int e = csc_ptr[j]; e < csc_ptr[j + 1]; ++e)
+                            if (win_off(j, csc_post[e]) < 0)
+                                emax = std::max(emax, (int)++rptr[(size_t)j * wpc +
+                                                                  lsm_lif::pair_wave_of_block(csc_post[e] >> 7, wpc) + 1]);
+                    if (emax > 64) continue;                             // one lane per list entry
+                    for (size_t q = 1; q < rptr.size(); ++q) rptr[q] += rptr[q - 1];
+                    if ((uint64_t)rptr.back() * 8u >= (1ull << 32)) continue;
+                    std::vector<uint2> rem(std::max<size_t>(1, rptr.back()));
+                    std::vector<uint32_t> fill(rptr.begin(), rptr.end() - 1);
+                    for (int j = 0; j < N; ++j)
+                        for (int e = csc_ptr[j]; e < csc_ptr[j + 1]; ++e) {
+                            const int i = csc_post[e];
+                            if (win_off(j, i) >= 0) continue;
+                            uint32_t bits;
+                            std::memcpy(&bits, &csc_w[e], 4);
+                            rem[fill[(size_t)j * wpc + lsm_lif::pair_wave_of_block(i >> 7, wpc)]++] =
+                                make_uint2(lsm_lif::pair_acc_byte(i), bits);
+                        }
+                    // the records carry device addresses (low halves): upload the lists first; a table that crosses a 4 GB
+                    // line (the kernel takes the high address bits from the table pointer) cannot serve this layout
+                    PairVariant &v = h->pvar[vi];
+                    if ((rc = upload(&v.rem, rem))) { free_reservoir(h); return rc; }
+                    const uint64_t band_a = reinterpret_cast<uint64_t>(h->band), rem_a = reinterpret_cast<uint64_t>(v.rem);
+                    if ((band_a >> 32) != ((band_a + (uint64_t)N * pitch) >> 32) ||
+                        (rem_a >> 32) != ((rem_a + (uint64_t)rem.size() * 8u) >> 32)) {
+                        (void)hipFree(v.rem);
+                        v.rem = nullptr;
+                        continue;
+                    }
+                    std::vector<uint4> rec((size_t)N * wpc);
+                    for (int j = 0; j < N; ++j) {
+                        const int q0 = a4v[j] >> 7, lead = a4v[j] & 127;
+                        for (int w = 0; w < wpc; ++w) {
+                            int ph = (w - q0) % wpc; ph += ph < 0 ? wpc : 0;
+                            int gb = q0 + ph; gb -= gb >= NB ? NB : 0;
+                            const size_t q = (size_t)j * wpc + w;
+                            rec[q] = lsm_lif::pair_record((uint32_t)(band_a + (uint64_t)j * pitch), (ph * 128 - lead) * 4, gb,
+                                                          (uint32_t)nbytes[j], (uint32_t)(rem_a + (uint64_t)rptr[q] * 8u),
+                                                          rptr[q + 1] - rptr[q]);
+                        }
+                    }
+                    std::vector<int> os(npad, -1);
+                    for (int o = 0; o < n_out; ++o) os[out_idx[o]] = o;
+                    std::vector<uint32_t> im((size_t)npad * 4, 0u);
+                    bool distinct = true;
+                    for (int c = 0; c < C; ++c)
+                        for (int d = 0; d < in_fanout; ++d) {
+                            const int tgt = in_tgt[(size_t)c * in_fanout + d];
+                            const int pc = coloured ? inperm[c] : c;
+                            uint32_t &word = im[(size_t)tgt * 4 + (pc >> 5)];
+                            distinct = distinct && !(word & (1u << (pc & 31)));
+                            word |= 1u << (pc & 31);
+                        }
+                    if (!distinct) { (void)hipFree(v.rem); v.rem = nullptr; continue; }
+                    if ((rc = upload(&v.rec, rec)) || (rc = upload(&v.oslot, os)) || (rc = upload(&v.inmask, im))) {
+                        free_reservoir(h);
+                        return rc;
+                    }
+                    v.incol = coloured;
+                    v.wpc = wpc; v.bl = bl; v.n_rem = rptr.back();
+                }
             }
         }
     }
@@ -558,6 +666,7 @@ int lsm_reservoir_create(lsm_reservoir **out, int num_neurons, int n_channels,
         if (has_ring(h) && (size_t)N * (size_t)h->ld * 4 > RING_AUTO_MIN_DENSE_BYTES)
             for (const auto &v : h->rvar)
                 if (v.wpc && ring_lds_bytes(h, v, 1024) <= 160 * 1024) ring_serves = true;
+        // (a pair-block layout implies strided quad layouts of the same table exist; the quads decide)
         if (!ring_serves && (rc = ensure_dense_rows(h))) { free_reservoir(h); return rc; }
     }
     *out = h;
@@ -569,8 +678,11 @@ extern "C" __attribute__((visibility("default")))
 int lsm_reservoir_set_kernel(lsm_reservoir *h, int mode)
 {
     LSM_REQUIRE(h != nullptr, "lsm_reservoir_set_kernel: null handle");
-    LSM_REQUIRE(mode >= 0 && mode <= 4, "mode must be 0 (auto), 1 (sparse), 2 (dense), 3 (ring) or 4 (ring, contiguous quads)");
+    LSM_REQUIRE(mode >= 0 && mode <= 6, "mode must be 0 (auto), 1 (sparse), 2 (dense), 3 (ring), 4 (ring, contiguous quads), "
+                "5 (ring, pair blocks) or 6 (ring, quads)");
     LSM_REQUIRE(mode < 3 || has_ring(h), "this reservoir has no ring-row format (not ring-like, or too small)");
+    LSM_REQUIRE(mode != 5 || has_pairs(h), "this reservoir has no pair-block ring layout (needs one leak coefficient, at most "
+                "128 channels, a block count that is a multiple of 4, 8 or 16 waves and a window of at most that many blocks)");
     if (mode == 2) {                       // an explicit request builds the table a ring-served reservoir deferred
         const int rc = ensure_dense_rows(h);
         if (rc) return rc;
@@ -633,6 +745,28 @@ static size_t ring_lds_bytes(const lsm_reservoir *h, const RingVariant &v, int T
            2 * npad * 2 + 512 + (size_t)h->n_out * 16 + (size_t)T * cw * 4;
 }
 
+static size_t pair_lds_bytes(const lsm_reservoir *h, const PairVariant &v, int T)
+{
+    const size_t npad = (size_t)v.bl * 128 * v.wpc;
+    const size_t cw = (size_t)(h->C + 31) / 32;
+    // dump words, float32 accumulators, 64 scratch words per wave, two step lists of bytes, block counts, feature
+    // accumulators, the clip's input bits
+    return (size_t)lsm_lif::PAIR_DUMP_BYTES + npad * 4 + (size_t)v.wpc * 256 + 2 * npad +
+           (size_t)lsm_lif::PAIR_WCNT_WORDS * 4 + (size_t)h->n_out * 16 + (size_t)T * cw * 4;
+}
+
+// Pair-block layout for a batch: the requested waves per clip, else the fewest waves (every wave repeats the per-row work).
+static const PairVariant *choose_pair(const lsm_reservoir *h, int T, int requested)
+{
+    if (h->mode != 0 && h->mode != 3 && h->mode != 5) return nullptr;
+    for (const auto &v : h->pvar) {
+        if (!v.wpc || pair_lds_bytes(h, v, T) > 160 * 1024) continue;
+        if (requested > 0 && v.wpc != requested) continue;
+        return &v;
+    }
+    return nullptr;
+}
+
 // Ring layout for a batch: the requested waves per clip, else a strided layout when the reservoir has one (every
 // wave gets one useful 1 KB window load per row: N=8000, 8 waves: 29.0 ms against 42.0 ms contiguous; N=4000:
 // 8 waves strided 9.7 ms against 4 fat waves contiguous 10.2 ms), and within a kind the layout with the fewest
@@ -647,6 +781,7 @@ static const RingVariant *choose_ring(const lsm_reservoir *h, int T, int request
         if (v4 != b4) return v4;
         return v4 ? v.wpc < b.wpc : v.wpc > b.wpc;
     };
+    if (h->mode == 5) return nullptr;             // pair blocks only
     for (const auto &v : h->rvar) {
         if (!v.wpc || ring_lds_bytes(h, v, T) > 160 * 1024) continue;
         if (v.strided && h->mode == 4) continue;
@@ -794,6 +929,7 @@ __global__ __launch_bounds__(256) void clip_rank_kernel(const int32_t *keys, int
 // Only an explicit ring request (modes 3, 4) is a hard error then.
 struct RunPlan {
     int kernel = 0;                   // 1 sparse, 2 dense rows, 3 ring rows
+    const PairVariant *pv = nullptr;  // ring rows in pair blocks (lif_pair.h) when set, else
     const RingVariant *rv = nullptr;
     const Variant *v = nullptr;
 };
@@ -801,6 +937,9 @@ struct RunPlan {
 static int make_plan(const lsm_reservoir *h, int n_clips, int n_steps, int waves_per_clip, RunPlan *p)
 {
     if (want_ring(h)) {
+        // pair blocks where the reservoir has them (cfg4: 5.1 -> see profiles/r05_*), else quads
+        p->pv = choose_pair(h, n_steps, waves_per_clip > 0 ? waves_per_clip : 0);
+        if (p->pv) { p->kernel = 3; return LSM_OK; }
         p->rv = choose_ring(h, n_steps, waves_per_clip > 0 ? waves_per_clip : 0);
         if (p->rv) { p->kernel = 3; return LSM_OK; }
         LSM_REQUIRE(h->mode < 3, "no ring-row layout for waves_per_clip=%d (N=%d, n_out=%d, T=%d): none fits a CU's "
@@ -854,6 +993,31 @@ static int reservoir_run(const lsm_reservoir *h, const uint8_t *spikes_u8, int n
             LSM_CHECK_HIP(hipGetLastError());
             order = ord;
         }
+    }
+    if (plan.kernel == 3 && plan.pv) {
+        const PairVariant *pv = plan.pv;
+        const int inmask = pv->incol ? 2 : 1;
+        lsm_lif::pair_fn_t pfn = pv->bl == 1 ? lsm_lif::pick_pair_1(pv->wpc, inmask)
+                                 : pv->bl == 2 ? lsm_lif::pick_pair_2(pv->wpc, inmask)
+                                 : pv->bl == 3 ? lsm_lif::pick_pair_3(pv->wpc, inmask)
+                                               : lsm_lif::pick_pair_4(pv->wpc, inmask);
+        LSM_REQUIRE(pfn != nullptr, "no pair-block ring kernel for BL=%d WPC=%d", pv->bl, pv->wpc);
+        lsm_lif::PairArgs r;
+        r.N = h->N; r.C = h->C; r.T = n_steps; r.B = n_clips;
+        r.n_out = h->n_out; r.CW = (int)cw;
+        r.refractory = h->refractory; r.burst_isi_max = h->burst_isi_max;
+        r.theta = h->theta; r.w_in = h->w_in; r.leak_u = h->leak_u;
+        r.raster = spikes_u8; r.band = h->band; r.rec = pv->rec; r.rem = pv->rem;
+        r.oslot = pv->oslot; r.inmask = pv->inmask; r.inperm = pv->incol ? h->inperm : nullptr;
+        r.n_keys = n_keys;
+        for (int k = 0; k < 8; ++k) r.key_ids[k] = k < n_keys ? key_ids[k] : 0;
+        r.features = features_out; r.spike_matrix = spike_matrix_out; r.v_trace = v_trace_out;
+        r.stats = stats_out; r.order = order;
+        const size_t lds = pair_lds_bytes(h, *pv, n_steps);
+        if (lds > 64 * 1024) lsm_allow_big_lds(reinterpret_cast<const void *>(pfn));
+        hipLaunchKernelGGL(pfn, dim3(n_clips), dim3(pv->wpc * 64), lds, (hipStream_t)stream, r);
+        LSM_CHECK_HIP(hipGetLastError());
+        return LSM_OK;
     }
     if (plan.kernel == 3) {
         const RingVariant *rv = plan.rv;
@@ -975,6 +1139,14 @@ int lsm_reservoir_plan(const lsm_reservoir *h, int n_clips, int n_steps, int wav
     const int rc = make_plan(h, n_clips, n_steps, waves_per_clip, &p);
     if (rc) return rc;
     if (kernel_out) *kernel_out = p.kernel;
+    if (p.kernel == 3 && p.pv) {
+        if (wpc_out) *wpc_out = p.pv->wpc;
+        if (slots_out) *slots_out = p.pv->bl * 2;
+        if (lds_bytes_out) *lds_bytes_out = (int)pair_lds_bytes(h, *p.pv, n_steps);
+        if (table_bytes_out)    // ring windows + this layout's lists + its row records
+            *table_bytes_out = (long)((size_t)h->N * h->band_pitch + p.pv->n_rem * 8 + (size_t)h->N * p.pv->wpc * 16);
+        return LSM_OK;
+    }
     if (p.kernel == 3) {
         if (wpc_out) *wpc_out = p.rv->wpc;
         if (slots_out) *slots_out = p.rv->ql * 4;
@@ -1000,6 +1172,7 @@ int lsm_reservoir_input_mode(const lsm_reservoir *h, int n_clips, int n_steps, i
     if (h == nullptr) return LSM_ERR_ARG;
     RunPlan p;
     if (make_plan(h, n_clips, n_steps, waves_per_clip, &p) != LSM_OK) return LSM_ERR_UNSUPPORTED;
+    if (p.kernel == 3 && p.pv) return p.pv->incol ? 15 : 14;
     if (p.kernel == 3) return p.rv->inmask ? (p.rv->incol ? 13 : 12) : (ring_inreg(*p.rv) ? 11 : 10);
     if (p.kernel == 1) return 20;
     return p.v->inmask ? (p.v->incol ? 3 : 2) : (lif_inreg(*p.v) ? 1 : 0);
@@ -1016,7 +1189,9 @@ int lsm_reservoir_row_request_bytes(const lsm_reservoir *h, int n_clips, int n_s
     const int rc = make_plan(h, n_clips, n_steps, waves_per_clip, &p);
     if (rc) return rc;
     const double n = (double)h->N;
-    if (p.kernel == 3)
+    if (p.kernel == 3 && p.pv)
+        *mean_bytes_out = (h->band_bytes_sum + (double)p.pv->n_rem * 8.0) / n + p.pv->wpc * 16.0;
+    else if (p.kernel == 3)
         *mean_bytes_out = (h->band_bytes_sum + (double)p.rv->n_rem * 8.0) / n + (p.rv->wpc + 1) * 4.0;
     else if (p.kernel == 2)
         *mean_bytes_out = (double)h->ld * 4.0;

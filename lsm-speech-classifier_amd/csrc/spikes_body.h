@@ -55,16 +55,22 @@ __device__ __forceinline__ void spec_to_spikes_body(const SpikeArgs<T> &a, const
     const int n = F * nc;
 
     T mx = -INFINITY, mn = INFINITY;
+    int nan_seen = 0;
     for (int i = threadIdx.x; i < n; i += blockDim.x) {
         const T v = db[i];
         mx = v > mx ? v : mx;
         mn = v < mn ? v : mn;
+        nan_seen |= v != v;
     }
     mx = block_reduce(mx, true, scratch);
     mn = block_reduce(mn, false, scratch);
+    // ndarray.max() / .min() / np.maximum (create_dataset.py:59-63) propagate NaN, the comparisons above skip it: one NaN
+    // among the dB values makes the maximum, the floor and the minimum NaN, hence every normalised value NaN and the
+    // raster all zeros (tests/golden/postfilter_nonfinite.npz: the reference's own output for such inputs)
+    if (__syncthreads_or(nan_seen)) mx = mn = (T)NAN;
     // create_dataset.py:60 floors at max-80 before the min is taken: min' = max(min, max-80)
     const T fl = a.apply_floor ? mx - (T)80.0 : -INFINITY;
-    const T lo = mn > fl ? mn : fl;
+    const T lo = (mn > fl || mn != mn) ? mn : fl;
     const T hi = mx;
     const bool flat = (hi - lo) < (T)1e-8;
     const T den = (hi - lo) + (T)1e-8;

@@ -164,7 +164,10 @@ class SNN:
         }
 
     # 'band': round-1 name of 'ring'; 'ring-contiguous': ring rows with contiguous quad ownership only (tests)
-    KERNEL_MODES = {"auto": 0, "sparse": 1, "dense": 2, "ring": 3, "band": 3, "ring-contiguous": 4}
+    # 'ring-pairs' / 'ring-quads': ring rows shared out in 128-neuron pair blocks (csrc/lif_pair.h) / in 256-neuron quads
+    # (csrc/lif_ring.h) only -- 'ring' takes pair blocks where the reservoir has them (tests, same-box A/B runs)
+    KERNEL_MODES = {"auto": 0, "sparse": 1, "dense": 2, "ring": 3, "band": 3, "ring-contiguous": 4, "ring-pairs": 5,
+                    "ring-quads": 6}
 
     def set_kernel(self, mode: str = "auto"):
         """'auto' (register accumulation over dense presynaptic rows; over ring rows -- dense ring window

@@ -68,15 +68,19 @@ ORC_API int orc_gammatone_spec(const float *audio, int n_samples, const double *
     return 0;
 }
 
-/* create_dataset.py:59-60: 20*log10(x + 1e-9), floored at (global max - 80). In place. */
+/* create_dataset.py:59-60: 20*log10(x + 1e-9), floored at (global max - 80). In place.
+ * spec_db.max() and np.maximum propagate NaN: one NaN value makes the maximum, the floor and with it every element NaN
+ * (tests/golden/postfilter_nonfinite.npz holds the reference's output for such inputs). */
 ORC_API void orc_gammatone_db(double *spec, int n)
 {
     double mx = -INFINITY;
+    int nan_seen = 0;
     for (int i = 0; i < n; ++i) {
         spec[i] = 20 * log10(spec[i] + 1e-9);
         if (spec[i] > mx) mx = spec[i];
+        nan_seen |= spec[i] != spec[i];
     }
-    const double fl = mx - 80.0;
+    const double fl = nan_seen ? (double)NAN : mx - 80.0;
     for (int i = 0; i < n; ++i) if (!(spec[i] >= fl)) spec[i] = fl;
 }
 
@@ -87,7 +91,9 @@ ORC_API int orc_normalise_resize_f64(const double *db, int n_filters, int ncols,
 {
     double lo = INFINITY, hi = -INFINITY;
     const int n = n_filters * ncols;
-    for (int i = 0; i < n; ++i) { if (db[i] < lo) lo = db[i]; if (db[i] > hi) hi = db[i]; }
+    int nan_seen = 0;
+    for (int i = 0; i < n; ++i) { if (db[i] < lo) lo = db[i]; if (db[i] > hi) hi = db[i]; nan_seen |= db[i] != db[i]; }
+    if (nan_seen) lo = hi = (double)NAN;      /* ndarray.min() / .max() propagate NaN (create_dataset.py:62-63) */
     if ((hi - lo) < 1e-8) {
         memset(out, 0, sizeof(double) * (size_t)n_filters * time_bins);
         return 1;
@@ -125,7 +131,9 @@ ORC_API int orc_normalise_resize_f32(const float *db, int n_filters, int ncols, 
 {
     float lo = INFINITY, hi = -INFINITY;
     const int n = n_filters * ncols;
-    for (int i = 0; i < n; ++i) { if (db[i] < lo) lo = db[i]; if (db[i] > hi) hi = db[i]; }
+    int nan_seen = 0;
+    for (int i = 0; i < n; ++i) { if (db[i] < lo) lo = db[i]; if (db[i] > hi) hi = db[i]; nan_seen |= db[i] != db[i]; }
+    if (nan_seen) lo = hi = NAN;              /* ndarray.min() / .max() propagate NaN (create_dataset.py:62-63) */
     if ((hi - lo) < 1e-8f) {
         memset(out, 0, sizeof(float) * (size_t)n_filters * time_bins);
         return 1;

@@ -145,9 +145,44 @@ def main():
         frontend=np.array([cd.SAMPLE_RATE, cd.DURATION, cd.TIME_BINS, cd.HYSTERESIS_GAP,
                            cd.MAX_SAMPLES_PER_CLASS, cd.REDUNDANCY_FACTOR], dtype=np.float64),
     )
+    nonfinite(cd, holder)
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)))
 
 
+def nonfinite(cd, holder):
+    """Round 5: the reference's post-filterbank code on spectrograms that hold a NaN or an Inf --
+    `spec_db.max()` / `.min()` / `np.maximum` (create_dataset.py:59-67) propagate NaN, so the whole clip normalises to NaN
+    (and its raster is all zeros).  Own random stream and own file: the other fixtures keep their bytes."""
+    rs = np.random.RandomState(20261005)
+    audio = np.zeros(16000, dtype=np.float32)
+    post = {}
+    with np.errstate(all="ignore"):
+        for name, F, pos, val in (("gt_nan", 16, (3, 17), np.nan), ("gt_nan_first", 8, (0, 0), np.nan),
+                                  ("gt_nan_last", 8, (7, 97), np.nan), ("gt_inf", 16, (5, 40), np.inf)):
+            spec = np.abs(rs.randn(F, 98)) * 1e-2
+            spec[pos] = val
+            holder["spec"] = spec
+            post[f"{name}_in"] = spec
+            post[f"{name}_out"] = cd.audio_to_spectrogram(audio, F, "gammatone")
+        for name, F, pos, val in (("mel_nan", 40, (11, 60), np.nan), ("mel_nan_first", 13, (0, 0), np.nan)):
+            db = np.maximum(-np.abs(rs.randn(F, 101)) * 25.0, -80.0).astype(np.float32)
+            db[rs.randint(F), rs.randint(101)] = 0.0
+            db[pos] = val
+            holder["spec"] = None
+            holder["db"] = db
+            post[f"{name}_in"] = db
+            post[f"{name}_out"] = cd.audio_to_spectrogram(audio, F, "mel")
+        for k in list(post):
+            if k.endswith("_out"):
+                post[k[:-4] + "_raster"] = cd.convert_spectrogram_to_spikes_hysteresis(
+                    post[k], cd.SPIKE_THRESHOLDS, cd.HYSTERESIS_GAP)
+    np.savez_compressed(os.path.join(OUT, "postfilter_nonfinite.npz"), **post)
+
+
 if __name__ == "__main__":
-    main()
+    if sys.argv[1:] == ["nonfinite"]:
+        cd_, _, holder_ = load_reference()
+        nonfinite(cd_, holder_)
+    else:
+        main()

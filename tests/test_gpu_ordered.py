@@ -167,7 +167,7 @@ def test_ring_rows_with_three_quads_per_wave(torch_cuda, oracle_c, n, k, want_wp
     res = R.build_reservoir(R.SimulationParams(num_neurons=n, num_output_neurons=n // 3, small_world_graph_k=k,
                                                mean_weight=wc * 1.3), c)
     net = snn.SNN(None, reservoir=res)
-    net.set_kernel("ring")
+    net.set_kernel("ring-quads")           # (round 5: "ring" would take the reservoir's pair-block layout, csrc/lif_pair.h)
     plan = net.plan(b, t, 0)
     assert plan["kernel"] == "ring" and plan["waves_per_clip"] == want_wpc and plan["slots_per_lane"] == 12
     feats, sm, vt = net.run_batch(rasters, KEYS, want_spike_matrix=True, want_v_trace=True)
