@@ -87,11 +87,13 @@ def parse_args(argv=None):
                     help="set-up, before the W warm-up steps: HotPath.prime() keeps the pipeline running untimed for this "
                          "long so that the timed steps see the clock a running pipeline holds, not the ramp after an idle "
                          "set-up phase (0 = one step per stream only)")
-    ap.add_argument("--exchange", default="chunked", choices=["chunked", "once", "per-step"],
-                    help="N > 1: 'chunked' = the rows of every --exchange-chunk steps travel in one all-gather on a stream "
-                         "of its own as soon as those steps have finished, so only the last chunk's gather is exposed "
-                         "behind the last step; 'once' = ONE all-gather after the last step, inside the timed region "
-                         "(what the product does per split, extract_lsm_features.py, where it is negligible); "
+    ap.add_argument("--exchange", default="once", choices=["chunked", "once", "per-step"],
+                    help="N > 1: 'once' (default) = ONE all-gather after the last step, inside the timed region -- what the "
+                         "product does per split (extract_lsm_features.py) and the only mode whose RCCL call pattern is "
+                         "a single collective on the current stream; 'chunked' = the rows of every --exchange-chunk steps "
+                         "travel in one all-gather on a stream of its own as soon as those steps have finished, so only "
+                         "the last chunk's gather is exposed behind the last step (rehearsed with ONE rank over RCCL and "
+                         "2-3 ranks over gloo only: opt-in until a run with >= 2 GPUs is on record, ADVICE r4); "
                          "'per-step' = an all-gather behind every step's reservoir kernel")
     ap.add_argument("--exchange-chunk", type=int, default=5, help="steps per all-gather of the chunked exchange")
     ap.add_argument("--tail-steps", type=int, default=None,
@@ -110,25 +112,44 @@ def spawn_ranks(n: int) -> int:
     the JSON line on the inherited stdout.  The children are POLLED: when one exits non-zero while others still
     sit in the rendezvous or a collective, the rest are terminated (then killed) and that status is returned at
     once instead of after the process-group timeout."""
+    import tempfile
     sock = socket.socket()                          # a free rendezvous port, held until the children are started
     sock.bind(("127.0.0.1", 0))
     port = sock.getsockname()[1]
-    procs = []
+    procs, errs = [], []
+
+    def replay(r, last=None):
+        """Rank r's stderr (its last `last` lines, or all of it) on this process's stderr."""
+        errs[r].flush()
+        errs[r].seek(0)
+        lines = errs[r].read().decode("utf-8", "replace").splitlines()
+        for l in (lines[-last:] if last else lines):
+            print(f"[rank {r}] {l}", file=sys.stderr)
+
     try:
         for r in range(n):
             env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n),
                        MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
             env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: what RCCL between processes needs on this driver
-            procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+            # every rank's stderr goes to a file of its own: when a rank dies, ITS last lines are what the parent shows
+            # (interleaved output of eight ranks hides which one failed and why)
+            errs.append(tempfile.TemporaryFile())
+            procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                          stderr=errs[r]))
         sock.close()          # rank 0 binds it seconds later (interpreter start + import torch); nobody else has the number
         rc = 0
         while True:
             codes = [p.poll() for p in procs]
-            bad = [abs(c) for c in codes if c not in (None, 0)]
+            bad = [(r, c) for r, c in enumerate(codes) if c not in (None, 0)]
             if bad:
-                rc = max(bad)
+                rc = max(abs(c) for _, c in bad)
+                for r, c in bad:
+                    print(f"bench.py: rank {r} of {n} exited with status {c}; its last stderr lines:", file=sys.stderr)
+                    replay(r, last=40)
                 break
             if all(c == 0 for c in codes):
+                for r in range(n):                  # nothing a rank said is lost: rank 0 in full, the others' last lines
+                    replay(r, last=None if r == 0 else 6)
                 return 0
             time.sleep(0.05)
     finally:
@@ -298,9 +319,18 @@ def run_rank(args):
         wc = float(t.item())
     params = reservoir.SimulationParams(num_neurons=cfg["N"], num_output_neurons=cfg["n_out"],
                                         small_world_graph_k=cfg["k"], mean_weight=wc * MULTIPLIER)
+    # per-rank set-up, timed: every rank builds the same wiring on its host cores and uploads it -- with eight ranks on one
+    # node this is the part of the run outside the timed region that a driver's timeout has to cover (VERDICT r4 #4b)
+    t_s0 = time.perf_counter()
     res = reservoir.build_reservoir(params, fe.n_channels)
+    t_s1 = time.perf_counter()
     net = snn.SNN(params, reservoir=res, device=dev)
     net.set_kernel(args.kernel)
+    torch.cuda.synchronize()
+    t_s2 = time.perf_counter()
+    setup_s = {"build_reservoir_s": round(t_s1 - t_s0, 3), "lsm_reservoir_create_s": round(t_s2 - t_s1, 3)}
+    print(f"bench.py[rank {rank}/{world}]: set-up {args.config}: build_reservoir {setup_s['build_reservoir_s']} s (host), "
+          f"lsm_reservoir_create + upload {setup_s['lsm_reservoir_create_s']} s", file=sys.stderr, flush=True)
     n_feat = len(FEATURE_SET) * cfg["n_out"]
 
     n_streams = args.streams or DEFAULT_STREAMS
@@ -550,14 +580,17 @@ def run_rank(args):
                        "inputs": "pinned host memory, copied every step" if args.from_host else "resident in HBM",
                        "host_enqueue_ms_per_step": round(host_enqueue_ms, 4),
                        "streams": hp.n_streams, "fe_streams": hp.n_fe_streams, "hw_queues": hp.hw_queues,
-                       "prime": f"{primed_steps} untimed steps (>= {args.prime_ms:g} ms) in HotPath.prime() before the "
-                                f"{args.warmup} warm-up steps",
+                       "prime": (f"{primed_steps} untimed steps (>= {args.prime_ms:g} ms) in HotPath.prime() before the "
+                                 f"{args.warmup} warm-up steps" +
+                                 ("; a whole unprimed pass (one step per stream, the warm-up steps and the timed steps, "
+                                  "reported as `unprimed`) ran before this one" if unprimed is not None else "")),
                        "tail_steps": f"the last {tail_steps} timed step(s) are submitted with tail=True (low-latency layouts), as "
                                      f"HotPath.run() submits the last batches of a finite list",
                        "pipeline": ("serial" if hp.n_streams <= 1 else
                                     "pipeline.HotPath: steps rotate over the streams" if not hp.n_fe_streams else
                                     "pipeline.HotPath: front ends on their own streams, reservoir launches behind events"),
                        "mean_output_spikes_per_clip": spikes_per_clip,
+                       "setup_s": setup_s,
                        "sharding": ((f"clips x{world}, feature rows all-gathered every {chunk} steps on a stream of their "
                                      f"own while the next steps run; only the last chunk's gather is exposed"
                                      if xs is not None else
@@ -572,6 +605,9 @@ def run_rank(args):
         # this rank's GPU work, waits for that work AND the other ranks; 0 without a process group).  end_* lie INSIDE the
         # timed region
         line["fences"] = res_pass["fences"]
+        if use_dist:                # what this rank's process saw: both are read once, when HIP / RCCL initialise
+            line["rank_env"] = {k: os.environ.get(k) for k in ("HSA_ENABLE_IPC_MODE_LEGACY", "GPU_MAX_HW_QUEUES",
+                                                               "MASTER_ADDR", "WORLD_SIZE")}
         if DIAG_IDLE_MS > 0:
             line["fences"]["diag_idle_ms_before_region"] = DIAG_IDLE_MS
         if use_dist and once and args.stage != "frontend":
@@ -590,6 +626,8 @@ def run_rank(args):
             per_clip = fe.n_channels * fe.n_steps + n_feat * 4 + fe.n_steps * w_bytes / B
             compulsory = fe.n_channels * fe.n_steps + n_feat * 4 + w_bytes / B
             kname = {"dense": "lif_dense_kernel", "ring": "lif_ring_kernel", "sparse": "lif_kernel"}[net.kernel_in_use()]
+            if net.plan(B, fe.n_steps, 0)["input_mode"] in (14, 15):
+                kname = "lif_pair_kernel"           # ring rows shared out in pair blocks (csrc/lif_pair.h)
             traffic = None
             tfile = os.environ.get("LSM_TRAFFIC_FILE") or os.path.join(ROOT, "profiles", "lif_traffic.json")
             tkey = f"{args.config}_B{B}_{net.kernel_in_use()}"
@@ -621,9 +659,17 @@ def run_rank(args):
                          "row-gather latency at the occupancy LDS and registers allow (table in the Infinity Cache, "
                          "bandwidth far from saturated)"),
                 "sparse": "ordered LDS read-modify-write chain per step"}[net.kernel_in_use()]
+            # `bound` names what bounds THIS kernel: "latency" = one clip's per-step dependency chain (table
+            # L2-resident), "gather" = the row gathers from the Infinity Cache / fabric, "hbm" would be streamed bytes.
+            # achieved / peak / frac stay SURVEY.md 8(d)'s streamed-bytes MODEL priced against the HBM peak (`model`);
+            # hbm_frac_measured is the counter traffic of a launch over its duration over that peak: what the memory
+            # side really moves.
+            bound = {"dense": "latency", "sparse": "latency",
+                     "ring": "gather" if plan["table_bytes"] > 40e6 else "latency"}[net.kernel_in_use()]
             line["roofline"] = {
-                "bound": "hbm", "kernel": kname, "achieved": round(achieved, 2),
+                "bound": bound, "model": "hbm", "kernel": kname, "achieved": round(achieved, 2),
                 "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
+                "hbm_frac_measured": None if traffic is None else round(traffic / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
                 "traffic": traffic, "traffic_source": traffic_source, "kernel_ms": round(k_ms, 4),
                 "kernel_ms_source": "lone launch of the batch in the library's own layout, HIP events on the launch "
                                     "stream, median of 5, measured in this run after the timed region",
@@ -700,8 +746,10 @@ def run_rank(args):
 def main():
     args = parse_args()
     launched = "RANK" in os.environ and "WORLD_SIZE" in os.environ
-    if args.gpus > 1 and not launched:
-        sys.exit(spawn_ranks(args.gpus))            # the parent never touches the GPU
+    # LSM_BENCH_FORCE_SPAWN=1: go through the launcher even for one rank (tests/test_gpu_bench_contract.py checks what a
+    # rank started by it inherits)
+    if (args.gpus > 1 or os.environ.get("LSM_BENCH_FORCE_SPAWN") == "1") and not launched:
+        sys.exit(spawn_ranks(max(1, args.gpus)))    # the parent never touches the GPU
     if os.environ.get("LSM_BENCH_SPAWN_ONLY") == "1" and launched:
         return spawn_check()
     run_rank(args)

@@ -687,6 +687,9 @@ LSM_API int lsm_gammatone_spec_f64(const float *audio, int n_clips, int n_sample
                                    void *stream)
 {
     LSM_REQUIRE(n_clips >= 0 && n_filters >= 1 && n_samples >= 1, "bad shape");
+    // SPEC.md 1.1: one channel would take NumPy's pairwise window sums in the reference; these kernels sum element by element
+    LSM_REQUIRE(n_filters >= 2, "the gammatone filterbank needs n_filters >= 2 (one channel: NumPy's pairwise window sums, "
+                "SPEC.md 1.1)");
     if (n_clips == 0) return LSM_OK;
     LSM_REQUIRE(audio && coefs, "gammatone: null input");
     LSM_REQUIRE(spec_out || db_out, "gammatone: both outputs null");
@@ -798,6 +801,9 @@ LSM_API int lsm_gammatone_spikes_f64(const float *audio, int n_clips, int n_samp
 {
     LSM_REQUIRE((launch_flags & ~3) == 0, "launch_flags: only bit 0 (low-latency layout) and bit 1 (no LDS reservation) are defined");
     LSM_REQUIRE(n_clips >= 0 && n_filters >= 1 && n_samples >= 1, "bad shape");
+    // SPEC.md 1.1: one channel would take NumPy's pairwise window sums in the reference; these kernels sum element by element
+    LSM_REQUIRE(n_filters >= 2, "the gammatone filterbank needs n_filters >= 2 (one channel: NumPy's pairwise window sums, "
+                "SPEC.md 1.1)");
     LSM_REQUIRE(nwin >= 1 && hop >= 1 && ncols >= 2 && time_bins >= 2, "bad window");
     LSM_REQUIRE(nwin <= NWIN_MAX * hop, "nwin=%d needs more than %d overlapping windows of hop=%d",
                 nwin, NWIN_MAX, hop);

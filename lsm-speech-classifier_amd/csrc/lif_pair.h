@@ -50,6 +50,43 @@ namespace lsm_lif {
 #define LSM_PAIR_MARK(k)
 #endif
 
+// Diagnostic builds only (results stay right): extra work per row and wave, to see which port the row loop is bound by
+// (profiles/r05_pair_issue_ports.txt): scalar / vector instructions, LDS stores to the lane's own dump word, buffer loads
+// whose descriptor holds zero bytes (they pass through the texture-address unit and touch no memory).
+#ifndef LSM_PAIR_DUMMY_SALU
+#define LSM_PAIR_DUMMY_SALU 0
+#endif
+#ifndef LSM_PAIR_DUMMY_VALU
+#define LSM_PAIR_DUMMY_VALU 0
+#endif
+#ifndef LSM_PAIR_DUMMY_LDS
+#define LSM_PAIR_DUMMY_LDS 0
+#endif
+#ifndef LSM_PAIR_DUMMY_VMEM
+#define LSM_PAIR_DUMMY_VMEM 0
+#endif
+#ifndef LSM_PAIR_OWN_DUMP
+#define LSM_PAIR_OWN_DUMP 0     // 1: a lane without a list entry adds its zero to a dump word of its own (lane*4), not to word 0
+#endif
+// Time-only ablation builds (VERDICT r4 #1a: "predict before building"; exp/r05_residency.py).  REPLAY: the update takes every
+// neuron's spike from a RECORDED spike matrix (the `spike_matrix` argument, read instead of written: a correct run's
+// output), so the rows of every step are those of the real run whatever else the build leaves out; features are garbage.
+// LEAN (with REPLAY): no input masks, no refractory/slot register, no feature records -- the registers and the LDS a
+// kernel would have with the input counts precomputed and the features accumulated outside LDS.
+#ifndef LSM_PAIR_REPLAY
+#define LSM_PAIR_REPLAY 0
+#endif
+#ifndef LSM_PAIR_LEAN
+#define LSM_PAIR_LEAN 0
+#endif
+#ifndef LSM_PAIR_WAVES_PER_EU
+#define LSM_PAIR_WAVES_PER_EU 4
+#endif
+#ifndef LSM_PAIR_LDS_PAD
+#define LSM_PAIR_LDS_PAD 0      // extra LDS bytes per clip (host side): pins the clips per compute unit of an ablation build
+#endif
+#define LSM_PAIR_DUMMIES (LSM_PAIR_DUMMY_SALU || LSM_PAIR_DUMMY_VALU || LSM_PAIR_DUMMY_LDS || LSM_PAIR_DUMMY_VMEM)
+
 struct PairArgs {
     int N, C, T, B;
     int n_out, CW, refractory, burst_isi_max;
@@ -135,7 +172,7 @@ __device__ __forceinline__ uint32_t pair_scan_max(uint32_t v)
 // BL: blocks (128 neurons, 2 per lane) per wave; WPC: waves per clip; INMASK: 1 = natural bit positions of the input
 // channels, 2 = coloured positions (lif_dense.h, INMODE 3).
 template <int BL, int WPC, int INMASK>
-__global__ __launch_bounds__(WPC * 64) __attribute__((amdgpu_waves_per_eu(4)))
+__global__ __launch_bounds__(WPC * 64) __attribute__((amdgpu_waves_per_eu(LSM_PAIR_WAVES_PER_EU)))
 void lif_pair_kernel(const PairArgs a)
 {
     constexpr int SL = 2 * BL;
@@ -152,8 +189,8 @@ void lif_pair_kernel(const PairArgs a)
     uint32_t *marks = reinterpret_cast<uint32_t *>(smem + PAIR_DUMP_BYTES + NPAD * 4);    // 64 words per wave
     uint8_t *wlist = reinterpret_cast<uint8_t *>(marks + WPC * 64);                       // 2*NPAD: 128 per block
     uint32_t *wcnt = reinterpret_cast<uint32_t *>(wlist + 2 * NPAD);                      // 2*64 block counts + stats
-    uint4 *feat = reinterpret_cast<uint4 *>(wcnt + PAIR_WCNT_WORDS);                      // n_out
-    uint32_t *bits = reinterpret_cast<uint32_t *>(feat + a.n_out);                        // T*CW
+    uint4 *feat = reinterpret_cast<uint4 *>(wcnt + PAIR_WCNT_WORDS);                      // n_out (none in a LEAN ablation build)
+    uint32_t *bits = reinterpret_cast<uint32_t *>(feat + (LSM_PAIR_LEAN ? 0 : a.n_out)); // T*CW
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -168,7 +205,8 @@ void lif_pair_kernel(const PairArgs a)
     // ---- prologue: zero LDS state, bit-pack the clip's raster time-major ----
     for (int i = tid; i < (PAIR_DUMP_BYTES + NPAD * 4 + WPC * 256) / 4; i += NT) reinterpret_cast<uint32_t *>(smem)[i] = 0u;
     for (int i = tid; i < PAIR_WCNT_WORDS; i += NT) wcnt[i] = 0u;
-    for (int i = tid; i < a.n_out; i += NT) feat[i] = make_uint4(0, 0, 0, 0);
+    if (!LSM_PAIR_LEAN)
+        for (int i = tid; i < a.n_out; i += NT) feat[i] = make_uint4(0, 0, 0, 0);
     for (int i = tid; i < T * CW; i += NT) bits[i] = 0u;
     __syncthreads();
     {
@@ -201,8 +239,8 @@ void lif_pair_kernel(const PairArgs a)
     // my neurons: register r = 2*q + h  <->  neuron GB(q)*128 + lane*2 + h
     // oref[r] = (output slot + 1) | (refractory countdown << 16), as in lif_ring.h
     float v[SL];
-    uint32_t oref[SL];
-    uint32_t im[SL][4];                             // channels 0..127 feeding my neuron r
+    uint32_t oref[LSM_PAIR_LEAN ? 1 : SL];
+    uint32_t im[LSM_PAIR_LEAN ? 1 : SL][4];         // channels 0..127 feeding my neuron r
     const float lam_u = a.leak_u;
 #pragma unroll
     for (int q = 0; q < BL; ++q) {
@@ -214,17 +252,26 @@ void lif_pair_kernel(const PairArgs a)
             // padding neurons (i >= N) start with a NaN potential: it stays NaN through every update and never fires
             // (a window that wraps past the ring's end may deliver weights of real blocks to them)
             v[2 * q + h] = (i0 + h) < N ? 0.0f : __builtin_nanf("");
-            oref[2 * q + h] = (uint32_t)(o[h] + 1);
-            const uint4 m = reinterpret_cast<const uint4 *>(a.inmask)[i0 + h];
-            im[2 * q + h][0] = m.x; im[2 * q + h][1] = m.y; im[2 * q + h][2] = m.z; im[2 * q + h][3] = m.w;
+            if (!LSM_PAIR_LEAN) {
+                oref[2 * q + h] = (uint32_t)(o[h] + 1);
+                const uint4 m = reinterpret_cast<const uint4 *>(a.inmask)[i0 + h];
+                im[2 * q + h][0] = m.x; im[2 * q + h][1] = m.y; im[2 * q + h][2] = m.z; im[2 * q + h][3] = m.w;
+            }
         }
     }
-    const uint32_t ref_set = (uint32_t)a.refractory << 16;
+    uint32_t ref_set_v = (uint32_t)a.refractory << 16;             // (vector registers: a VOP3 select takes no literal)
+    uint32_t minus_one_v = 0xFFFF0000u;
+    asm volatile("" : "+v"(ref_set_v), "+v"(minus_one_v));
     const float theta = a.theta, w_in = a.w_in;
-    const bool trace = a.spike_matrix != nullptr || a.v_trace != nullptr;
+    const bool trace = !LSM_PAIR_REPLAY && (a.spike_matrix != nullptr || a.v_trace != nullptr);
+#if LSM_PAIR_REPLAY
+    const uint8_t *rec_row = a.spike_matrix + (size_t)b * a.T * a.N;      // recorded spikes of step t (read, not written)
+    unsigned long long never64 = 0ull;
+    asm volatile("" : "+s"(never64));
+#endif
     // row t of the clip's optional (T, N) outputs: advanced by N per step (the per-block form of the address, a 64-bit
     // product, was computed by every block of every step, traced or not)
-    uint8_t *sm_row = a.spike_matrix ? a.spike_matrix + (size_t)b * T * N : nullptr;
+    uint8_t *sm_row = (a.spike_matrix && !LSM_PAIR_REPLAY) ? a.spike_matrix + (size_t)b * T * N : nullptr;
     float *vt_row = a.v_trace ? a.v_trace + (size_t)b * T * N : nullptr;
     const uint32_t lane8 = (uint32_t)lane * 8u;
     const uint32_t accl = (uint32_t)PAIR_DUMP_BYTES + lane8;       // my pair of block g: accl + g*512
@@ -298,30 +345,74 @@ void lif_pair_kernel(const PairArgs a)
             // the accumulators under the row being applied are fetched one row ahead: two sets, by the row's parity
             pair_f2 old[2];                      // under the window piece
             float oldl[2];                       // under my list entry
-#define LSM_PAIR_LOAD(p, m)                                                                     \
+#if LSM_PAIR_DUMMIES
+            uint32_t dummy_s_ = 0u, dummy_v_ = 0u;
+            pair_u2 dummy_m_[LSM_PAIR_P][LSM_PAIR_DUMMY_VMEM ? LSM_PAIR_DUMMY_VMEM : 1];
+#define LSM_PAIR_DUMMY_WORK                                                                                     \
+    {                                                                                                           \
+        _Pragma("unroll") for (int d_ = 0; d_ < LSM_PAIR_DUMMY_SALU; ++d_)                                      \
+            asm volatile("s_add_u32 %0, %0, 1" : "+s"(dummy_s_) : : "scc");                                     \
+        _Pragma("unroll") for (int d_ = 0; d_ < LSM_PAIR_DUMMY_VALU; ++d_)                                      \
+            asm volatile("v_add_u32 %0, 1, %0" : "+v"(dummy_v_));                                               \
+        _Pragma("unroll") for (int d_ = 0; d_ < LSM_PAIR_DUMMY_LDS; ++d_)                                       \
+            asm volatile("ds_write_b32 %0, %1" : : "v"(lane8 >> 1), "v"(dummy_v_) : "memory"); /* dump bytes */ \
+    }
+            // the zero-byte loads take a buffer of the row pipeline like the real ones (issued with the row, consumed when the
+            // row is applied): waiting for one at once would drain the pipeline and measure that instead
+#define LSM_PAIR_DUMMY_LOADS(p)                                                                                 \
+    {                                                                                                           \
+        _Pragma("unroll") for (int d_ = 0; d_ < LSM_PAIR_DUMMY_VMEM; ++d_) {                                    \
+            const __amdgpu_buffer_rsrc_t rd_ = __builtin_amdgcn_make_buffer_rsrc(                               \
+                reinterpret_cast<void *>(band_hi | (uint64_t)sx), 0, 0, RSRC_FLAGS);                            \
+            dummy_m_[p][d_] = __builtin_amdgcn_raw_buffer_load_b64(rd_, (int)lane8, 0, 0);                      \
+        }                                                                                                       \
+    }
+#define LSM_PAIR_DUMMY_USE(p)                                                                                   \
+    {                                                                                                           \
+        _Pragma("unroll") for (int d_ = 0; d_ < LSM_PAIR_DUMMY_VMEM; ++d_) asm volatile("" : : "v"(dummy_m_[p][d_])); \
+    }
+#else
+#define LSM_PAIR_DUMMY_WORK
+#define LSM_PAIR_DUMMY_LOADS(p)
+#define LSM_PAIR_DUMMY_USE(p)
+#endif
+            // SEL(m): the six fields of the chunk's row m into scalar registers.  It runs AHEAD of the row's loads, with the
+            // previous row's accumulator update between them: a buffer load that reads a scalar register written by
+            // v_readlane needs five wait states, which were three s_nop per row when the loads followed at once.
+            uint32_t sx, snb, sw, sln, slo, so;
+#define LSM_PAIR_SEL(m)                                                                         \
     {                                                                                           \
         const int mm = (m);                                                                     \
-        const uint32_t sx = __builtin_amdgcn_readlane(rx, mm);                                  \
-        const uint32_t snb = __builtin_amdgcn_readlane(r_nb, mm);                               \
-        const uint32_t sw = __builtin_amdgcn_readlane(rw, mm);                                  \
-        const uint32_t sln = __builtin_amdgcn_readlane(r_ln, mm);                               \
+        sx = __builtin_amdgcn_readlane(rx, mm);                                                 \
+        snb = __builtin_amdgcn_readlane(r_nb, mm);                                              \
+        sw = __builtin_amdgcn_readlane(rw, mm);                                                 \
+        sln = __builtin_amdgcn_readlane(r_ln, mm);                                              \
+        slo = __builtin_amdgcn_readlane(r_lo, mm);                                              \
+        so = __builtin_amdgcn_readlane(r_so, mm);                                               \
+        __builtin_amdgcn_sched_barrier(0);                                                      \
+    }
+            // ISSUE(p): request the selected row's window piece and list entry into buffer p
+#define LSM_PAIR_ISSUE(p)                                                                       \
+    {                                                                                           \
+        LSM_PAIR_DUMMY_WORK                                                                     \
         const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc(                    \
             reinterpret_cast<void *>(band_hi | (uint64_t)sx), 0, (int)snb, RSRC_FLAGS);         \
-        wa[p] = lane8 + __builtin_amdgcn_readlane(r_lo, mm);                                    \
+        wa[p] = lane8 + slo;                                                                    \
         /* the whole byte offset goes through the VGPR (opaque scalar: nothing is folded into the  */ \
         /* instruction's immediate), so a lane in front of the row is a huge unsigned offset        */ \
-        uint32_t so = __builtin_amdgcn_readlane(r_so, mm);                                      \
-        asm volatile("" : "+s"(so));                                                            \
+        uint32_t so_ = so;                                                                      \
+        asm volatile("" : "+s"(so_));                                                           \
         if (LSM_PAIR_ABLATE & 1) {                                                              \
             wv[p] = (pair_f2){0.0f, 0.0f};                                                      \
         } else {                                                                                \
-            const pair_u2 x = __builtin_amdgcn_raw_buffer_load_b64(rb, (int)(lane8 + so), 0, 0); \
+            const pair_u2 x = __builtin_amdgcn_raw_buffer_load_b64(rb, (int)(lane8 + so_), 0, 0); \
             wv[p] = (pair_f2){__uint_as_float(x.x), __uint_as_float(x.y)};                      \
         }                                                                                       \
         const __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc(                    \
             reinterpret_cast<void *>(rem_hi | (uint64_t)sw), 0, (int)sln, RSRC_FLAGS);          \
         if (LSM_PAIR_ABLATE & 8) re[p] = (pair_u2){0u, 0u};                                     \
         else re[p] = __builtin_amdgcn_raw_buffer_load_b64(rr, (int)lane8, 0, 0);                \
+        LSM_PAIR_DUMMY_LOADS(p)                                                                 \
         __builtin_amdgcn_sched_barrier(0);                                                      \
     }
             // READ(p): fetch the accumulators the row in buffer p adds to: the pair under its window piece and the word
@@ -330,6 +421,7 @@ void lif_pair_kernel(const PairArgs a)
 #define LSM_PAIR_READ(p)                                                                        \
     {                                                                                           \
         old[(p) & 1] = LSM_PAIR_LDS_F2(wa[p] + PAIR_DUMP_BYTES);                                \
+        if (LSM_PAIR_OWN_DUMP) re[p].x = max(re[p].x, lane8 >> 1);                              \
         oldl[(p) & 1] = LSM_PAIR_LDS_F1(re[p].x);                                               \
         __builtin_amdgcn_sched_barrier(0);                                                      \
     }
@@ -338,6 +430,7 @@ void lif_pair_kernel(const PairArgs a)
             // old + weight from the list write, in that order).  Rows are applied in ascending j = the order of these calls.
 #define LSM_PAIR_APPLY(p)                                                                       \
     {                                                                                           \
+        LSM_PAIR_DUMMY_USE(p)                                                                   \
         if (!(LSM_PAIR_ABLATE & 2)) {                                                           \
             /* the list sum first: its read was issued last, so ONE wait covers both reads */   \
             float newl = oldl[(p) & 1] + __uint_as_float(re[p].y);                              \
@@ -351,7 +444,10 @@ void lif_pair_kernel(const PairArgs a)
     }
             static_assert(P % 2 == 0, "the look-ahead sets alternate by the row's parity");
 #pragma unroll
-            for (int p = 0; p < P; ++p) LSM_PAIR_LOAD(p, p)
+            for (int p = 0; p < P; ++p) {
+                LSM_PAIR_SEL(p)
+                LSM_PAIR_ISSUE(p)
+            }
             LSM_PAIR_MARK(2)           // first P rows requested
             LSM_PAIR_READ(0)
             // whole groups of P rows, then the chunk's last n % P rows on their own (a clip with 5 rows in a step applies 5,
@@ -360,9 +456,10 @@ void lif_pair_kernel(const PairArgs a)
             for (; m + P <= n; m += P) {
 #pragma unroll
                 for (int p = 0; p < P; ++p) {
+                    LSM_PAIR_SEL(m + p + P)
                     LSM_PAIR_APPLY(p)
                     LSM_PAIR_READ((p + 1) % P)
-                    LSM_PAIR_LOAD(p, m + p + P)
+                    LSM_PAIR_ISSUE(p)
                 }
             }
             const int rest = n - m;
@@ -373,7 +470,11 @@ void lif_pair_kernel(const PairArgs a)
                     LSM_PAIR_APPLY(p)
                 }
             LSM_PAIR_MARK(3)           // rows applied (waits for the row loads included)
-#undef LSM_PAIR_LOAD
+#undef LSM_PAIR_SEL
+#undef LSM_PAIR_ISSUE
+#undef LSM_PAIR_DUMMY_WORK
+#undef LSM_PAIR_DUMMY_LOADS
+#undef LSM_PAIR_DUMMY_USE
 #undef LSM_PAIR_READ
 #undef LSM_PAIR_APPLY
         }
@@ -399,11 +500,17 @@ void lif_pair_kernel(const PairArgs a)
             *reinterpret_cast<pair_f2 *>(smem + accl + (uint32_t)gb * 512u) = (pair_f2){0.0f, 0.0f};
             float ci[2] = {cq.x, cq.y};
             unsigned long long bq[2];
+#if LSM_PAIR_REPLAY
+            uint32_t rec2 = 0u;                                     // my two neurons' recorded spikes of this step
+            if (gb * 128 + lane * 2 + 1 < N) rec2 = *reinterpret_cast<const uint16_t *>(rec_row + gb * 128 + lane * 2);
+#endif
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
                 const int r = 2 * q + h;
                 uint32_t nn;
-                if (INMASK == 2) {
+                if (LSM_PAIR_LEAN) {
+                    nn = 0u;
+                } else if (INMASK == 2) {
                     // disjoint by construction of the bit positions: one popcount of the union (lif_dense.h, INMODE 3)
                     uint32_t u = im[r][0] & rowbits[0];
 #pragma unroll
@@ -418,12 +525,26 @@ void lif_pair_kernel(const PairArgs a)
                 const float m = lam_u * v[r];
                 const float d = v[r] - m;
                 const float vn = d + ci[h];
+#if LSM_PAIR_REPLAY
+                const unsigned long long held = LSM_PAIR_LEAN ? 0ull : __builtin_amdgcn_uicmp(oref[r], 0x10000u, 35);
+                const unsigned long long ge = __builtin_amdgcn_fcmpf(vn, theta, 3 /* ordered >= */);
+                // (the membrane arithmetic stays alive through a mask the compiler cannot see is empty)
+                const unsigned long long fire = __builtin_amdgcn_uicmp((rec2 >> (8 * h)) & 0xFFu, 0u, 33 /* != */) |
+                                                (ge & ~held & never64);
+#else
                 const unsigned long long held = __builtin_amdgcn_uicmp(oref[r], 0x10000u, 35 /* unsigned >= */);
                 const unsigned long long ge = __builtin_amdgcn_fcmpf(vn, theta, 3 /* ordered >= */);
                 const unsigned long long fire = ge & ~held;
+#endif
                 v[r] = __builtin_amdgcn_inverse_ballot_w64(ge | held) ? 0.0f : vn;
-                oref[r] += __builtin_amdgcn_inverse_ballot_w64(held) ? 0xFFFF0000u
-                           : (__builtin_amdgcn_inverse_ballot_w64(fire) ? ref_set : 0u);
+                // countdown: -1 while held, set on fire -- two selects on the lane masks and an add (written out: the
+                // compiler turned the nested select into an exec-masked region of six instructions)
+                if (!LSM_PAIR_LEAN) {
+                    uint32_t dlt;
+                    asm("v_cndmask_b32_e64 %0, 0, %1, %2" : "=v"(dlt) : "v"(ref_set_v), "s"(fire));
+                    asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(dlt) : "v"(dlt), "v"(minus_one_v), "s"(held));
+                    oref[r] += dlt;
+                }
                 bq[h] = fire;
             }
             int nq = 0;
@@ -437,7 +558,7 @@ void lif_pair_kernel(const PairArgs a)
                         list_cur[gb * 128 + rank] = (uint8_t)(lane * 2 + h);
                         rank += 1;
                         hf |= 1u << r;
-                        const int osl = (int)(oref[r] & 0xFFFFu) - 1;
+                        const int osl = LSM_PAIR_LEAN ? -1 : (int)(oref[r] & 0xFFFFu) - 1;
                         if (osl >= 0 && !(LSM_PAIR_ABLATE & 32)) {
                             uint4 f = feat[osl];
                             uint32_t nf = f.x & 0xFFFFu, bursts = f.x >> 16;
@@ -471,6 +592,9 @@ void lif_pair_kernel(const PairArgs a)
             }
         }
         if (lane < BL) wcnt[cur * PAIR_MAX_BLOCKS + lane * WPC + w] = cntv;      // block lane*WPC + w is my block `lane`
+#if LSM_PAIR_REPLAY
+        rec_row += N;
+#endif
         if (trace) {
             if (sm_row) sm_row += N;
             if (vt_row) vt_row += N;
@@ -494,7 +618,7 @@ void lif_pair_kernel(const PairArgs a)
         }
     }
     const int nf = a.n_keys * a.n_out;
-    for (int idx = tid; idx < nf; idx += NT) {
+    for (int idx = tid; idx < (LSM_PAIR_LEAN ? 0 : nf); idx += NT) {
         const int kq = idx / a.n_out;
         const int o = idx - kq * a.n_out;
         const uint4 f = feat[o];

@@ -752,7 +752,8 @@ static size_t pair_lds_bytes(const lsm_reservoir *h, const PairVariant &v, int T
     // dump words, float32 accumulators, 64 scratch words per wave, two step lists of bytes, block counts, feature
     // accumulators, the clip's input bits
     return (size_t)lsm_lif::PAIR_DUMP_BYTES + npad * 4 + (size_t)v.wpc * 256 + 2 * npad +
-           (size_t)lsm_lif::PAIR_WCNT_WORDS * 4 + (size_t)h->n_out * 16 + (size_t)T * cw * 4;
+           (size_t)lsm_lif::PAIR_WCNT_WORDS * 4 + (LSM_PAIR_LEAN ? 0 : (size_t)h->n_out * 16) + (size_t)T * cw * 4 +
+           (size_t)LSM_PAIR_LDS_PAD;
 }
 
 // Pair-block layout for a batch: the requested waves per clip, else the fewest waves (every wave repeats the per-row work).

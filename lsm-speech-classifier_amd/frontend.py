@@ -118,9 +118,18 @@ class SpikeFrontEnd:
     def __init__(self, n_filters: int, filterbank: str = "gammatone", device=None,
                  redundancy: int = REDUNDANCY_FACTOR, thresholds=None, gap: float = HYSTERESIS_GAP,
                  time_bins: int = TIME_BINS, n_samples: int = int(SAMPLE_RATE * DURATION)):
-        _lib.require_gpu()
         if filterbank not in ("gammatone", "mel"):
             raise ValueError(f"filterbank must be 'mel' or 'gammatone', got {filterbank!r}")
+        if int(n_filters) < 1:
+            raise ValueError(f"n_filters must be >= 1, got {n_filters}")
+        if filterbank == "gammatone" and int(n_filters) == 1:
+            # SPEC.md 1.1: with ONE gammatone channel NumPy sums each 400-sample window pairwise (the fancy-index result
+            # (1, 400) is contiguous along the reduced axis), with two or more element by element; the kernels implement
+            # the latter.  One filter is refused rather than answered 6e-16 beside the reference.
+            raise ValueError("the gammatone branch needs n_filters >= 2: with a single channel the reference's window sums "
+                             "take NumPy's pairwise order, which the GPU filterbank does not restate (SPEC.md 1.1); use "
+                             "--filterbank mel for one filter")
+        _lib.require_gpu()
         self.lib = _lib.load()
         self.device = torch.device(device if device is not None else "cuda")
         if self.device.type == "cuda" and self.device.index is None:      # pin the device NOW: later calls may

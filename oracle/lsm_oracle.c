@@ -31,9 +31,34 @@ ORC_API int orc_version(void) { return 1; }
  *     y = z0 + b0*x;  z0 = (z1 + x*b1) - y*a1;  z1 = x*b2 - y*a2
  * in float64, output divided by the channel gain, squared, then for every column the SEQUENTIAL
  * ascending sum of nwin samples (NumPy reduces the F-ordered fancy-index result that way for
- * F >= 2), / nwin, sqrt.
+ * F >= 2; for F == 1 it sums pairwise, restated below: the product refuses one gammatone filter), / nwin, sqrt.
  * coefs rows: [A0, A11, A12, A13, A14, A2, B0, B1, B2, gain], B0 == 1.
  * -------------------------------------------------------------------------------------------*/
+/* NumPy's pairwise summation of a contiguous float64 run (numpy/core/src/umath/loops_utils.h, pairwise_sum_DOUBLE):
+ * below 8 elements a plain loop, up to 128 eight interleaved partial sums combined as ((r0+r1)+(r2+r3))+((r4+r5)+(r6+r7))
+ * plus the tail, above that two halves, the first a multiple of 8 long. */
+static double np_pairwise_sum(const double *a, long n)
+{
+    if (n < 8) {
+        double res = 0.0;
+        for (long i = 0; i < n; ++i) res += a[i];
+        return res;
+    }
+    if (n <= 128) {
+        double r[8];
+        long i;
+        for (int j = 0; j < 8; ++j) r[j] = a[j];
+        for (i = 8; i < n - (n % 8); i += 8)
+            for (int j = 0; j < 8; ++j) r[j] += a[i + j];
+        double res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+        for (; i < n; ++i) res += a[i];
+        return res;
+    }
+    long n2 = n / 2;
+    n2 -= n2 % 8;
+    return np_pairwise_sum(a, n2) + np_pairwise_sum(a + n2, n - n2);
+}
+
 ORC_API int orc_gammatone_spec(const float *audio, int n_samples, const double *coefs,
                                int n_filters, int nwin, int hop, int ncols, double *out)
 {
@@ -60,7 +85,10 @@ ORC_API int orc_gammatone_spec(const float *audio, int n_samples, const double *
         for (int c = 0; c < ncols; ++c) {
             const double *seg = xe + (size_t)c * hop;
             double acc = seg[0];
-            for (int i = 1; i < nwin; ++i) acc += seg[i];
+            /* one filter: the fancy-index result (1, nwin) is contiguous along the reduced axis and NumPy sums it
+             * PAIRWISE; two and more filters: element by element, starting from the first */
+            if (n_filters == 1) acc = np_pairwise_sum(seg, nwin);
+            else for (int i = 1; i < nwin; ++i) acc += seg[i];
             out[(size_t)ch * ncols + c] = sqrt(acc / (double)nwin);
         }
     }

@@ -194,11 +194,13 @@ def test_bench_rccl_code_path_with_one_rank():
     env.pop("LSM_BENCH_BACKEND", None)
     env.pop("GPU_MAX_HW_QUEUES", None)        # this process's package import set 12; a fresh process under a launcher chooses
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "6", "--warmup", "2",
-                        "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=600)
+                        "--no-cpu-baseline", "--exchange", "chunked"], env=env, capture_output=True, text=True, timeout=600)
     assert p.returncode == 0, p.stderr[-3000:]
     d = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1])
     assert d["n_gpus"] == 1 and d["value"] > 1e4 and d["steps"] == 6
-    # the default exchange on RCCL: chunks of 5 steps on the exchange stream + the tail chunk, 16 hardware queues
+    # the chunked exchange on RCCL (opt-in since round 5; the default is the product's single exchange, whose one-rank
+    # run is tests/test_gpu_bench_contract.py::test_a_rank_started_by_the_launcher_inherits_what_rccl_needs): chunks of
+    # 5 steps on the exchange stream + the tail chunk, 16 hardware queues
     assert d["exchange"]["mode"] == "chunked" and d["exchange"]["chunk_steps"] == 5 and d["config"]["hw_queues"] == 16
     assert 0.0 <= d["exchange"]["exchange_ms"] < 5.0 and d["exchange"]["digest"] != 0
     # enqueueing a chunk's collective never waits for the GPU (the pipeline must keep running under it)

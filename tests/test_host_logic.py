@@ -13,10 +13,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def test_library_exports_every_declared_symbol():
     """The built liblsm_hip.so must load here (no GPU needed) and export every function that
-    include/lsm_hip.h declares -- no compute call is made."""
+    include/lsm_hip.h declares -- no compute call is made.  (_lib.load() itself rebuilds a library that is absent or was
+    built from other sources than the tree's.)"""
     from lsm_speech_classifier_amd import _lib, build
-    if not os.path.exists(build.lib_path()):
-        build.build()
     header = open(os.path.join(ROOT, "include", "lsm_hip.h")).read()
     declared = set(re.findall(r"^\s*(?:const\s+char\s*\*|int|long)\s*\*?\s*(lsm_[a-z0-9_]+)\s*\(", header, re.M))
     assert len(declared) >= 12
@@ -24,7 +23,33 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), f"{name} declared in lsm_hip.h but not exported"
     assert declared == set(_lib.EXPORTED_SYMBOLS)
-    assert lib.lsm_version() >= 100
+    assert lib.lsm_version() == build.version_number() >= 100
+    # the library says which sources it was built from, and that is this tree
+    assert lib.lsm_build_id().decode() == "LSM_BUILD_ID=" + build.source_id() and build.built_id() == build.source_id()
+
+
+def test_a_library_built_from_other_sources_is_refused(tmp_path):
+    """A stale binary must not pass for a build of the sources beside it: a copy of the library whose embedded build id
+    is altered is refused by the loader (auto-rebuild off), with both ids in the message."""
+    from lsm_speech_classifier_amd import build
+    blob = open(build.lib_path(), "rb").read()
+    mark = b"LSM_BUILD_ID=" + build.source_id().encode()
+    assert blob.count(mark) >= 1
+    bad = blob.replace(mark, b"LSM_BUILD_ID=" + b"0" * 24)
+    pkg = tmp_path / "pkg"
+    import shutil
+    shutil.copytree(os.path.join(ROOT, "lsm-speech-classifier_amd"), pkg, ignore=shutil.ignore_patterns("build", "__pycache__"))
+    (pkg / "liblsm_hip.so").write_bytes(bad)
+    shutil.copytree(os.path.join(ROOT, "include"), tmp_path / "include")         # part of what the build id hashes
+    code = ("import importlib.util, sys, os\n"
+            "os.environ['LSM_NO_AUTO_BUILD'] = '1'\n"
+            "spec = importlib.util.spec_from_file_location('lsm_speech_classifier_amd', %r, submodule_search_locations=[%r])\n"
+            "m = importlib.util.module_from_spec(spec); sys.modules['lsm_speech_classifier_amd'] = m; spec.loader.exec_module(m)\n"
+            "from lsm_speech_classifier_amd import _lib\n"
+            "try:\n    _lib.load()\nexcept _lib.LsmHipError as e:\n    print('REFUSED', 'other sources' in str(e), '0' * 24 in str(e))\n"
+            ) % (str(pkg / "__init__.py"), str(pkg))
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert "REFUSED True True" in out.stdout, out.stdout + out.stderr
 
 
 def test_no_gpu_means_loud_failure():
@@ -38,6 +63,16 @@ def test_no_gpu_means_loud_failure():
         snn.SNN(reservoir.SimulationParams(num_neurons=64, small_world_graph_k=8), n_channels=4)
     with pytest.raises(_lib.LsmHipError):
         frontend.convert_spectrogram_to_spikes_hysteresis(np.zeros((2, 5)), [0.5], 0.1)
+
+
+def test_one_gammatone_filter_is_refused_with_the_reason():
+    """SPEC.md 1.1: with one channel the reference's window sums take NumPy's pairwise order, which the GPU filterbank does
+    not restate: refused before anything touches the GPU (no GPU needed to see the message)."""
+    from lsm_speech_classifier_amd import frontend
+    with pytest.raises(ValueError, match="n_filters >= 2"):
+        frontend.SpikeFrontEnd(1, "gammatone")
+    with pytest.raises(ValueError, match="filterbank must be"):
+        frontend.SpikeFrontEnd(8, "bark")
 
 
 def test_missing_library_is_an_error_not_a_fallback():
