@@ -13,7 +13,7 @@ for n in (1536, 2048, 3072):
     net = snn.SNN(None, reservoir=R.build_reservoir(p, 128))
     dev = torch.from_numpy(rasters).cuda()
     ref = None
-    for kernel in ("dense", "ring-contiguous", "ring"):
+    for kernel in ("dense", "ring-contiguous", "ring-quads", "ring"):       # (round 5: "ring" = pair blocks where the reservoir has them)
         try:
             net.set_kernel(kernel)
         except Exception as e:

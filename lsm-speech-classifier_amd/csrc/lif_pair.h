@@ -65,6 +65,9 @@ namespace lsm_lif {
 #ifndef LSM_PAIR_DUMMY_VMEM
 #define LSM_PAIR_DUMMY_VMEM 0
 #endif
+#ifndef LSM_PAIR_DUMMY_VMEM_LANES
+#define LSM_PAIR_DUMMY_VMEM_LANES 64
+#endif
 #ifndef LSM_PAIR_OWN_DUMP
 #define LSM_PAIR_OWN_DUMP 0     // 1: a lane without a list entry adds its zero to a dump word of its own (lane*4), not to word 0
 #endif
@@ -167,6 +170,30 @@ __device__ __forceinline__ uint32_t pair_scan_max(uint32_t v)
     v = max(v, pair_dpp0<0x142, 0xA>(v));
     v = max(v, pair_dpp0<0x143, 0xC>(v));
     return v;
+}
+
+// SPEC.md 4: one feature of an output neuron from its exact integers (n spikes, first / last spike time, S1 = sum of the
+// spike times, Q = sum of the squared inter-spike intervals, bursts), evaluated in float64 and rounded to float32.
+__device__ __forceinline__ float pair_feature_value(int key, int n, int bursts, int first, int last, uint32_t s1, uint32_t q2,
+                                                    int T)
+{
+    double val = 0.0;
+    switch (key) {
+    case 0: val = (double)n; break;
+    case 1: { const double p = (double)n / (double)T; val = p * (1.0 - p); } break;
+    case 2: val = n >= 1 ? (double)s1 / (double)n : 0.0; break;
+    case 3: val = n >= 1 ? (double)first : 0.0; break;
+    case 4: val = n >= 1 ? (double)last : 0.0; break;
+    case 5: val = n >= 2 ? (double)(last - first) / (double)(n - 1) : 0.0; break;
+    case 6:
+        if (n >= 2) {
+            const double m = (double)(last - first) / (double)(n - 1);
+            val = (double)q2 / (double)(n - 1) - m * m;
+        }
+        break;
+    default: val = (double)bursts; break;
+    }
+    return (float)val;
 }
 
 // BL: blocks (128 neurons, 2 per lane) per wave; WPC: waves per clip; INMASK: 1 = natural bit positions of the input
@@ -347,7 +374,7 @@ void lif_pair_kernel(const PairArgs a)
             float oldl[2];                       // under my list entry
 #if LSM_PAIR_DUMMIES
             uint32_t dummy_s_ = 0u, dummy_v_ = 0u;
-            pair_u2 dummy_m_[LSM_PAIR_P][LSM_PAIR_DUMMY_VMEM ? LSM_PAIR_DUMMY_VMEM : 1];
+            pair_u2 dummy_m_[LSM_PAIR_P][LSM_PAIR_DUMMY_VMEM ? LSM_PAIR_DUMMY_VMEM : 1] = {};
 #define LSM_PAIR_DUMMY_WORK                                                                                     \
     {                                                                                                           \
         _Pragma("unroll") for (int d_ = 0; d_ < LSM_PAIR_DUMMY_SALU; ++d_)                                      \
@@ -364,7 +391,9 @@ void lif_pair_kernel(const PairArgs a)
         _Pragma("unroll") for (int d_ = 0; d_ < LSM_PAIR_DUMMY_VMEM; ++d_) {                                    \
             const __amdgpu_buffer_rsrc_t rd_ = __builtin_amdgcn_make_buffer_rsrc(                               \
                 reinterpret_cast<void *>(band_hi | (uint64_t)sx), 0, 0, RSRC_FLAGS);                            \
-            dummy_m_[p][d_] = __builtin_amdgcn_raw_buffer_load_b64(rd_, (int)lane8, 0, 0);                      \
+            /* LSM_PAIR_DUMMY_VMEM_LANES: only that many lanes take part (exec mask): does a load's cost follow its lanes? */ \
+            if (LSM_PAIR_DUMMY_VMEM_LANES >= 64 || lane < LSM_PAIR_DUMMY_VMEM_LANES)                            \
+                dummy_m_[p][d_] = __builtin_amdgcn_raw_buffer_load_b64(rd_, (int)lane8, 0, 0);                  \
         }                                                                                                       \
     }
 #define LSM_PAIR_DUMMY_USE(p)                                                                                   \
@@ -469,7 +498,6 @@ void lif_pair_kernel(const PairArgs a)
                     if (p > 0) LSM_PAIR_READ(p)
                     LSM_PAIR_APPLY(p)
                 }
-            LSM_PAIR_MARK(3)           // rows applied (waits for the row loads included)
 #undef LSM_PAIR_SEL
 #undef LSM_PAIR_ISSUE
 #undef LSM_PAIR_DUMMY_WORK
@@ -477,6 +505,7 @@ void lif_pair_kernel(const PairArgs a)
 #undef LSM_PAIR_DUMMY_USE
 #undef LSM_PAIR_READ
 #undef LSM_PAIR_APPLY
+            LSM_PAIR_MARK(3)           // rows applied (waits for the row loads included)
         }
         wave_lds_fence();
         uint32_t rowbits[4];                                    // this step's input bit row (wave-uniform)
@@ -624,23 +653,7 @@ void lif_pair_kernel(const PairArgs a)
         const uint4 f = feat[o];
         const int n = (int)(f.x & 0xFFFFu), bursts = (int)(f.x >> 16);
         const int first = (int)(f.y & 0xFFFFu), last = (int)(f.y >> 16);
-        double val = 0.0;
-        switch (a.key_ids[kq]) {
-        case 0: val = (double)n; break;
-        case 1: { const double p = (double)n / (double)T; val = p * (1.0 - p); } break;
-        case 2: val = n >= 1 ? (double)f.z / (double)n : 0.0; break;
-        case 3: val = n >= 1 ? (double)first : 0.0; break;
-        case 4: val = n >= 1 ? (double)last : 0.0; break;
-        case 5: val = n >= 2 ? (double)(last - first) / (double)(n - 1) : 0.0; break;
-        case 6:
-            if (n >= 2) {
-                const double m = (double)(last - first) / (double)(n - 1);
-                val = (double)f.w / (double)(n - 1) - m * m;
-            }
-            break;
-        default: val = (double)bursts; break;
-        }
-        a.features[(size_t)b * nf + idx] = (float)val;
+        a.features[(size_t)b * nf + idx] = pair_feature_value(a.key_ids[kq], n, bursts, first, last, f.z, f.w, T);
     }
 #if LSM_PAIR_PHASES
     __syncthreads();

@@ -164,7 +164,7 @@ __global__ __launch_bounds__(256) void power_to_db_kernel(const float *__restric
 // raster (lsm_fe::spec_to_spikes_body, the code of the split path).  No workgroup ever waits for another one: the
 // count is one atomic add whose returned value says who is last (the pattern MI355X_MICROARCH.md tabulates for a
 // consumer "told by the value its add returned"; the adder's stores are made visible by the fence before the add,
-// the finisher's loads are ordered by the fence after it).  The counters come in zero and leave zero.
+// the finisher's loads are ordered by the fence after it).  The launch function zeroes the counters on the stream first.
 struct MelSpikeArgs {
     MelArgs mel;                        // power_out = the power workspace (n_clips, n_mels, n_frames)
     lsm_fe::SpikeArgs<float> sp;        // db = the dB workspace, same shape: written and read by the finishing workgroup
@@ -291,6 +291,10 @@ LSM_API int lsm_mel_spikes_f32(const float *audio, int n_clips, int n_samples, i
 #endif
     fpw = fpw > n_frames ? n_frames : fpw;
     a.frames_per_wg = fpw;
+    // The per-clip arrival counters are zeroed HERE, on the launch stream (4 bytes per clip; a memset node when captured): the
+    // kernel resets a counter only when a clip's last workgroup arrives, so a launch that failed, or a workspace the caller
+    // did not zero, would otherwise leave every later launch without a finishing workgroup.
+    LSM_CHECK_HIP(hipMemsetAsync(a.counters, 0, (size_t)n_clips * sizeof(unsigned int), (hipStream_t)stream));
     hipLaunchKernelGGL(mel_spikes_kernel, dim3((n_frames + fpw - 1) / fpw, n_clips), dim3(256), 0, (hipStream_t)stream, a);
     LSM_CHECK_HIP(hipGetLastError());
     return LSM_OK;

@@ -763,6 +763,12 @@ static const PairVariant *choose_pair(const lsm_reservoir *h, int T, int request
     for (const auto &v : h->pvar) {
         if (!v.wpc || pair_lds_bytes(h, v, T) > 160 * 1024) continue;
         if (requested > 0 && v.wpc != requested) continue;
+        // Unless pair blocks are asked for by name, they are taken where they pay: with at least three blocks per wave.
+        // Same box, 512 clips, k = 0.2 N (profiles/r05_midsize_pairs_vs_quads.txt): N = 1536 (3 blocks, 4 waves) 1.33 ms
+        // against 2.95 in quads, N = 4000 (4 blocks) 4.17 against 5.10, N = 3072 (3 blocks, 8 waves) 3.47 against 3.45 --
+        // but N = 2048 (2 blocks, 8 waves) 2.46 against 2.19: with few neurons per lane the per-wave work per row dominates
+        // and the quads' four fat waves win.
+        if (h->mode != 5 && v.bl < 3 && has_ring(h)) continue;
         return &v;
     }
     return nullptr;

@@ -106,9 +106,14 @@ class MelSpectrogram:
         need = self.workspace_bytes(B)
         stream = torch.cuda.current_stream(self.device).cuda_stream
         if workspace is None:
-            ws = self._ws.get((B, stream))         # launches on ONE stream run in order: they may share a workspace
+            # launches on ONE stream run in order: they may share a workspace.  Keyed by the stream OBJECT (a raw handle
+            # can be handed out again after its stream has died) and bounded: the oldest entry goes
+            key = (B, torch.cuda.current_stream(self.device))
+            ws = self._ws.get(key)
             if ws is None:
-                ws = self._ws[(B, stream)] = self.new_workspace(B)
+                while len(self._ws) >= 16:
+                    self._ws.pop(next(iter(self._ws)))
+                ws = self._ws[key] = self.new_workspace(B)
         else:
             ws = workspace
             if ws.dtype != torch.uint8 or ws.numel() < need or ws.device != raster.device or ws.data_ptr() % 256:

@@ -303,8 +303,17 @@ class HotPath:
         """Feature rows of every batch, in order, as one (n_clips, n_feat) device tensor.  `audio_batches`
         is an iterable of (B_i, n_samples) arrays/tensors (host or device)."""
         self.fork_from_current()
-        batches = list(audio_batches)
-        parts = [self.submit(a, tail=i >= len(batches) - TAIL_STEPS)[0] for i, a in enumerate(batches)]
+        # The last TAIL_STEPS batches are submitted in the low-latency layouts: that needs a look-ahead of TAIL_STEPS
+        # batches, not the whole list -- a lazily produced stream of (pinned or device) batches is consumed as it comes and
+        # never held in full (ADVICE r4).
+        from collections import deque
+        parts, ahead, it = [], deque(), iter(audio_batches)
+        for a in it:
+            ahead.append(a)
+            if len(ahead) > TAIL_STEPS:
+                parts.append(self.submit(ahead.popleft(), tail=False)[0])
+        while ahead:
+            parts.append(self.submit(ahead.popleft(), tail=True)[0])
         self.synchronize()
         if not parts:
             n_keys = len(self.feature_keys) if self.feature_keys is not None else 8

@@ -198,7 +198,13 @@ class SNN:
         return {"kernel": {1: "sparse", 2: "dense", 3: "ring"}[k.value], "waves_per_clip": wpc.value,
                 "slots_per_lane": sl.value, "lds_bytes": lds.value, "table_bytes": tab.value,
                 "row_request_bytes": rb.value,
-                "input_mode": int(self.lib.lsm_reservoir_input_mode(self._handle, n_clips, n_steps, waves_per_clip))}
+                "input_mode": self._input_mode(n_clips, n_steps, waves_per_clip)}
+
+    def _input_mode(self, n_clips: int, n_steps: int, waves_per_clip: int) -> int:
+        mode = int(self.lib.lsm_reservoir_input_mode(self._handle, n_clips, n_steps, waves_per_clip))
+        if mode < 0:                         # an LSM_ERR_* code is not a mode
+            _lib.check(mode, "lsm_reservoir_input_mode")
+        return mode
 
     def layout(self, n_clips: int, n_steps: int, waves_per_clip: int = 0):
         wpc, sl, lds = C.c_int(), C.c_int(), C.c_int()

@@ -79,7 +79,10 @@ def _full_config(torch, oracle_c, n_filters, audio_kind, N, k, n_out, B, n_oracl
     f2, _, _ = net.run_batch(rasters[perm], KEYS)
     assert torch.equal(f2, feats[perm])
     del f2
-    for kernel in ("dense", "sparse"):                       # the other two kernels agree on the whole batch
+    others = ["dense", "sparse"]
+    if N == 4000:                                            # cfg4 runs on pair blocks (csrc/lif_pair.h): the quad form
+        others = ["ring-quads"] + others                     # (csrc/lif_ring.h) must agree on the whole batch too
+    for kernel in others:                                    # the other kernels agree on the whole batch
         net.set_kernel(kernel)
         st2 = torch.empty_like(stats)
         fk, _, _ = net.run_batch(rasters, KEYS, stats_out=st2)

@@ -58,7 +58,7 @@ def test_random_configurations_match_the_oracle(torch_cuda, oracle_c, seed, n_ca
         kernels = ["dense", "sparse"]
         try:
             net.set_kernel("ring")
-            kernels += ["ring", "ring-contiguous"]
+            kernels += ["ring", "ring-quads", "ring-contiguous"]
         except _lib.LsmHipError:
             pass                                       # not ring-like enough, or too small, for ring rows
         for kernel in kernels:

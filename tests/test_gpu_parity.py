@@ -261,7 +261,9 @@ def _kernels(net):
     out = ["dense", "sparse"]
     try:
         net.set_kernel("ring")
-        out[1:1] = ["ring", "ring-contiguous"]       # both quad ownerships (the second: contiguous layouts only)
+        # "ring": what the library prefers (pair blocks where the reservoir has them); "ring-quads" / "ring-contiguous":
+        # both quad ownerships of csrc/lif_ring.h (the second: contiguous layouts only)
+        out[1:1] = ["ring", "ring-quads", "ring-contiguous"]
     except _lib.LsmHipError:
         pass
     net.set_kernel("auto")
@@ -402,7 +404,8 @@ def test_full_size_properties(torch_cuda, oracle_c):
     assert "ring" in kernels
     for kernel in kernels:                                               # kernels and layouts agree
         net.set_kernel(kernel)
-        for wpc in ((2, 4) if kernel.startswith("ring") else (1, 4, 16)):   # (ring rows at N=1000: 2 or 4 waves)
+        # (ring rows at N=1000: quads on 2 or 4 waves, pair blocks -- 8 blocks of 128 -- on 4 or 8)
+        for wpc in ((2, 4) if kernel in ("ring-quads", "ring-contiguous") else (4,) if kernel == "ring" else (1, 4, 16)):
             fw, _, _ = net.run_batch(dev, waves_per_clip=wpc)
             np.testing.assert_array_equal(fw.cpu().numpy(), f)
     net.set_kernel("auto")
@@ -546,7 +549,7 @@ def test_ring_rows_at_quad_multiples(torch_cuda, oracle_c, n, k, c, t):
     net = snn.SNN(None, reservoir=res)
     assert "ring" in _kernels(net)
     ran = 0
-    for kernel in ("ring", "ring-contiguous", "dense"):
+    for kernel in [k for k in _kernels(net) if k != "sparse"]:
         net.set_kernel(kernel)
         for wpc in (0, 2, 4, 8, 16):
             if kernel == "dense" and wpc not in (0, 16):
