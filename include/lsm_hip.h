@@ -241,7 +241,8 @@ int lsm_reservoir_row_request_bytes(const lsm_reservoir *h, int n_clips, int n_s
  * popcounts, 3 = channel masks at coloured bit positions, one popcount (C <= 128 and an assignment exists in which
  * the channels feeding one neuron differ mod 32); ring rows 10 = packed entries streamed, 11 = packed entries in
  * registers, 12 / 13 = per-neuron channel masks at natural / coloured positions (C <= 128, every neuron the same leak
- * coefficient, strided quad ownership with at most two quads per wave); sparse kernel 20. */
+ * coefficient, strided quad ownership with at most two quads per wave), 14 / 15 = the same masks in the pair-block form of the
+ * ring rows (C <= 128; any leak coefficients); sparse kernel 20. */
 int lsm_reservoir_input_mode(const lsm_reservoir *h, int n_clips, int n_steps, int waves_per_clip);
 
 /* Diagnostic builds (-DLSM_STAMP=1) only: per-phase s_memtime sums of the reservoir kernel

@@ -23,8 +23,9 @@
 //     had four.
 // Arithmetic, order of the float32 additions (rows ascending, a target gets a row's weight from the window or from
 // the list, never both, the other term is +0.0) and results are those of lif_ring.h: bit-identical to the oracle.
-// The kernel exists for the input drive counted from per-neuron channel masks (uniform leak, C <= 128: the
-// reference's defaults); other reservoirs keep lif_ring.h.
+// The kernel exists for the input drive counted from per-neuron channel masks (C <= 128: the reference's 128 filters), with
+// one leak coefficient for every neuron (its default) or one per neuron in registers (LEAKV: --leak-variance-divisor);
+// other reservoirs keep lif_ring.h.
 #pragma once
 #include "lif_kernel.h"
 
@@ -98,6 +99,7 @@ struct PairArgs {
     const float *band;         // ring windows, row j at byte j*pitch (the table of lif_ring.h)
     const uint4 *rec;          // (N*WPC) row records (pair_record), built for the addresses of `band` and `rem`
     const uint2 *rem;          // list entries {LDS byte offset of the target's accumulator, weight bits}, (row, wave) major
+    const float *leak;         // LEAKV: (NPAD) leak coefficient per neuron, neuron order (else null: leak_u for every neuron)
     const int *oslot;          // (NPAD) output slot or -1, neuron order
     const uint32_t *inmask;    // (NPAD, 4) input-channel bit mask per neuron
     const uint8_t *inperm;     // coloured positions: (C) bit position of channel c in the input bit row, else null
@@ -198,7 +200,9 @@ __device__ __forceinline__ float pair_feature_value(int key, int n, int bursts, 
 
 // BL: blocks (128 neurons, 2 per lane) per wave; WPC: waves per clip; INMASK: 1 = natural bit positions of the input
 // channels, 2 = coloured positions (lif_dense.h, INMODE 3).
-template <int BL, int WPC, int INMASK>
+// LEAKV: a leak coefficient per neuron in registers (the reference's --leak-variance-divisor, extract_lsm_features.py:174,
+// 182-183) instead of one for all (its default).
+template <int BL, int WPC, int INMASK, bool LEAKV = false>
 __global__ __launch_bounds__(WPC * 64) __attribute__((amdgpu_waves_per_eu(LSM_PAIR_WAVES_PER_EU)))
 void lif_pair_kernel(const PairArgs a)
 {
@@ -266,6 +270,7 @@ void lif_pair_kernel(const PairArgs a)
     // my neurons: register r = 2*q + h  <->  neuron GB(q)*128 + lane*2 + h
     // oref[r] = (output slot + 1) | (refractory countdown << 16), as in lif_ring.h
     float v[SL];
+    float lam[LEAKV ? SL : 1];
     uint32_t oref[LSM_PAIR_LEAN ? 1 : SL];
     uint32_t im[LSM_PAIR_LEAN ? 1 : SL][4];         // channels 0..127 feeding my neuron r
     const float lam_u = a.leak_u;
@@ -274,6 +279,10 @@ void lif_pair_kernel(const PairArgs a)
         const int i0 = LSM_PAIR_GB(q) * 128 + lane * 2;
         const int2 o2 = *reinterpret_cast<const int2 *>(a.oslot + i0);
         const int o[2] = {o2.x, o2.y};
+        if (LEAKV) {
+            const float2 l2 = *reinterpret_cast<const float2 *>(a.leak + i0);
+            lam[2 * q] = l2.x; lam[2 * q + 1] = l2.y;
+        }
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
             // padding neurons (i >= N) start with a NaN potential: it stays NaN through every update and never fires
@@ -551,7 +560,7 @@ void lif_pair_kernel(const PairArgs a)
                          __popc(im[r][2] & rowbits[2]) + __popc(im[r][3] & rowbits[3]);
                 }
                 ci[h] = ci[h] + w_in * (float)nn;          // SPEC.md §3: input term after the recurrent sum
-                const float m = lam_u * v[r];
+                const float m = (LEAKV ? lam[r] : lam_u) * v[r];
                 const float d = v[r] - m;
                 const float vn = d + ci[h];
 #if LSM_PAIR_REPLAY
@@ -666,23 +675,27 @@ void lif_pair_kernel(const PairArgs a)
 
 typedef void (*pair_fn_t)(const PairArgs);
 
-template <int BL, int INMASK>
+template <int BL, int INMASK, bool LEAKV>
 pair_fn_t pick_pair_wpc(int wpc)
 {
     switch (wpc) {
-    case 4: return lif_pair_kernel<BL, 4, INMASK>;
-    case 8: return lif_pair_kernel<BL, 8, INMASK>;
-    case 16: return lif_pair_kernel<BL, 16, INMASK>;
+    case 4: return lif_pair_kernel<BL, 4, INMASK, LEAKV>;
+    case 8: return lif_pair_kernel<BL, 8, INMASK, LEAKV>;
+    case 16: return lif_pair_kernel<BL, 16, INMASK, LEAKV>;
     default: return nullptr;
     }
 }
 template <int BL>
-pair_fn_t pick_pair(int wpc, int inmask) { return inmask == 2 ? pick_pair_wpc<BL, 2>(wpc) : pick_pair_wpc<BL, 1>(wpc); }
+pair_fn_t pick_pair(int wpc, int inmask, bool leakv)
+{
+    if (leakv) return inmask == 2 ? pick_pair_wpc<BL, 2, true>(wpc) : pick_pair_wpc<BL, 1, true>(wpc);
+    return inmask == 2 ? pick_pair_wpc<BL, 2, false>(wpc) : pick_pair_wpc<BL, 1, false>(wpc);
+}
 
 // one definition per translation unit lif_pair_<bl>.hip
-pair_fn_t pick_pair_1(int wpc, int inmask);
-pair_fn_t pick_pair_2(int wpc, int inmask);
-pair_fn_t pick_pair_3(int wpc, int inmask);
-pair_fn_t pick_pair_4(int wpc, int inmask);
+pair_fn_t pick_pair_1(int wpc, int inmask, bool leakv);
+pair_fn_t pick_pair_2(int wpc, int inmask, bool leakv);
+pair_fn_t pick_pair_3(int wpc, int inmask, bool leakv);
+pair_fn_t pick_pair_4(int wpc, int inmask, bool leakv);
 
 }  // namespace lsm_lif

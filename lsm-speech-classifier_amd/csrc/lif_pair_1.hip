@@ -2,5 +2,5 @@
 #include "lif_pair.h"
 
 namespace lsm_lif {
-pair_fn_t pick_pair_1(int wpc, int inmask) { return pick_pair<1>(wpc, inmask); }
+pair_fn_t pick_pair_1(int wpc, int inmask, bool leakv) { return pick_pair<1>(wpc, inmask, leakv); }
 }  // namespace lsm_lif

@@ -70,6 +70,7 @@ struct PairVariant {        // per waves-per-clip layout of the pair-block ring 
     uint4 *rec = nullptr;            // (N*wpc) row records (lsm_lif::pair_record)
     uint2 *rem = nullptr;            // {LDS byte offset of the accumulator, weight bits}, (row, wave) major
     int *oslot = nullptr;
+    float *leak = nullptr;           // (npad) leak coefficients when they differ between neurons, else null
     uint32_t *inmask = nullptr;      // (npad, 4) input-channel masks in neuron order
     bool incol = false;              // the masks use the coloured bit positions of lsm_reservoir::inperm
 };
@@ -146,6 +147,7 @@ static int free_reservoir(lsm_reservoir *h)
         if (v.rec) (void)hipFree(v.rec);
         if (v.rem) (void)hipFree(v.rem);
         if (v.oslot) (void)hipFree(v.oslot);
+        if (v.leak) (void)hipFree(v.leak);
         if (v.inmask) (void)hipFree(v.inmask);
     }
     delete h;
@@ -573,7 +575,7 @@ int lsm_reservoir_create(lsm_reservoir **out, int num_neurons, int n_channels,
                 // Pair blocks (lif_pair.h): the same windows shared out in 128-neuron blocks, wave w owning the blocks
                 // w, w+wpc, ...: the residues must survive the ring's wrap (2*NQ % wpc == 0), a window must not touch more
                 // than wpc blocks, a wave at most four blocks (8 neurons per lane).  The kernel counts the input drive from
-                // per-neuron channel masks only: one leak coefficient for every neuron and C <= 128.
+                // per-neuron channel masks only: C <= 128.
 #if LSM_EXPERIMENT_HOOKS
                 static const bool no_pairs = [] { const char *e = getenv("LSM_RING_NO_PAIRS"); return e && atoi(e) != 0; }();
 #else
@@ -583,7 +585,7 @@ int lsm_reservoir_create(lsm_reservoir **out, int num_neurons, int n_channels,
                 int wsb = 0;
                 for (int j = 0; j < N; ++j) wsb = std::max(wsb, (((a4v[j] & 127) + (nbytes[j] / 4 - 1)) >> 7) + 1);
                 const int pwpcs[3] = {4, 8, 16};
-                for (int vi = 0; vi < 3 && !no_pairs && C <= 128 && h->leak_uniform; ++vi) {
+                for (int vi = 0; vi < 3 && !no_pairs && C <= 128; ++vi) {
                     const int wpc = pwpcs[vi];
                     if (NB % wpc != 0 || wsb > wpc) continue;
                     const int bl = NB / wpc;
@@ -650,6 +652,11 @@ int lsm_reservoir_create(lsm_reservoir **out, int num_neurons, int n_channels,
                         free_reservoir(h);
                         return rc;
                     }
+                    if (!h->leak_uniform) {                              // a coefficient per neuron (LEAKV form of the kernel)
+                        std::vector<float> lk(npad, 0.0f);
+                        for (int i = 0; i < N; ++i) lk[i] = leak[i];
+                        if ((rc = upload(&v.leak, lk))) { free_reservoir(h); return rc; }
+                    }
                     v.incol = coloured;
                     v.wpc = wpc; v.bl = bl; v.n_rem = rptr.back();
                 }
@@ -681,8 +688,8 @@ int lsm_reservoir_set_kernel(lsm_reservoir *h, int mode)
     LSM_REQUIRE(mode >= 0 && mode <= 6, "mode must be 0 (auto), 1 (sparse), 2 (dense), 3 (ring), 4 (ring, contiguous quads), "
                 "5 (ring, pair blocks) or 6 (ring, quads)");
     LSM_REQUIRE(mode < 3 || has_ring(h), "this reservoir has no ring-row format (not ring-like, or too small)");
-    LSM_REQUIRE(mode != 5 || has_pairs(h), "this reservoir has no pair-block ring layout (needs one leak coefficient, at most "
-                "128 channels, a block count that is a multiple of 4, 8 or 16 waves and a window of at most that many blocks)");
+    LSM_REQUIRE(mode != 5 || has_pairs(h), "this reservoir has no pair-block ring layout (needs at most 128 channels, a block "
+                "count that is a multiple of 4, 8 or 16 waves and a window of at most that many blocks)");
     if (mode == 2) {                       // an explicit request builds the table a ring-served reservoir deferred
         const int rc = ensure_dense_rows(h);
         if (rc) return rc;
@@ -1004,10 +1011,11 @@ static int reservoir_run(const lsm_reservoir *h, const uint8_t *spikes_u8, int n
     if (plan.kernel == 3 && plan.pv) {
         const PairVariant *pv = plan.pv;
         const int inmask = pv->incol ? 2 : 1;
-        lsm_lif::pair_fn_t pfn = pv->bl == 1 ? lsm_lif::pick_pair_1(pv->wpc, inmask)
-                                 : pv->bl == 2 ? lsm_lif::pick_pair_2(pv->wpc, inmask)
-                                 : pv->bl == 3 ? lsm_lif::pick_pair_3(pv->wpc, inmask)
-                                               : lsm_lif::pick_pair_4(pv->wpc, inmask);
+        const bool leakv = pv->leak != nullptr;
+        lsm_lif::pair_fn_t pfn = pv->bl == 1 ? lsm_lif::pick_pair_1(pv->wpc, inmask, leakv)
+                                 : pv->bl == 2 ? lsm_lif::pick_pair_2(pv->wpc, inmask, leakv)
+                                 : pv->bl == 3 ? lsm_lif::pick_pair_3(pv->wpc, inmask, leakv)
+                                               : lsm_lif::pick_pair_4(pv->wpc, inmask, leakv);
         LSM_REQUIRE(pfn != nullptr, "no pair-block ring kernel for BL=%d WPC=%d", pv->bl, pv->wpc);
         lsm_lif::PairArgs r;
         r.N = h->N; r.C = h->C; r.T = n_steps; r.B = n_clips;
@@ -1015,7 +1023,7 @@ static int reservoir_run(const lsm_reservoir *h, const uint8_t *spikes_u8, int n
         r.refractory = h->refractory; r.burst_isi_max = h->burst_isi_max;
         r.theta = h->theta; r.w_in = h->w_in; r.leak_u = h->leak_u;
         r.raster = spikes_u8; r.band = h->band; r.rec = pv->rec; r.rem = pv->rem;
-        r.oslot = pv->oslot; r.inmask = pv->inmask; r.inperm = pv->incol ? h->inperm : nullptr;
+        r.oslot = pv->oslot; r.leak = pv->leak; r.inmask = pv->inmask; r.inperm = pv->incol ? h->inperm : nullptr;
         r.n_keys = n_keys;
         for (int k = 0; k < 8; ++k) r.key_ids[k] = k < n_keys ? key_ids[k] : 0;
         r.features = features_out; r.spike_matrix = spike_matrix_out; r.v_trace = v_trace_out;

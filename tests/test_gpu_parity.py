@@ -492,7 +492,12 @@ def test_ring_rows_count_inputs_from_masks_or_entries(torch_cuda, oracle_c, divi
     net = snn.SNN(None, reservoir=res)
     net.set_kernel("ring")
     mode = net.plan(2, t, 8)["input_mode"]
-    assert mode in ((12, 13, 14, 15) if divisor is None and channels <= 128 else (10, 11)), mode
+    # (round 5: 14 / 15 = the masks in the pair-block kernel, csrc/lif_pair.h, which also holds a leak coefficient per neuron)
+    assert mode in ((12, 13, 14, 15) if channels <= 128 else (10, 11)), mode
+    net.set_kernel("ring-quads")
+    assert net.plan(2, t, 8)["input_mode"] in ((12, 13) if divisor is None and channels <= 128 else (10, 11))
+    assert _check_against_oracle(net, rasters, oracle_c, 8) > 1
+    net.set_kernel("ring")
     ran = 0
     for wpc in (0, 8, 16):
         ran += _check_against_oracle(net, rasters, oracle_c, wpc) > 1
