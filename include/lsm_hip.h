@@ -245,6 +245,16 @@ int lsm_reservoir_row_request_bytes(const lsm_reservoir *h, int n_clips, int n_s
  * ring rows (C <= 128; any leak coefficients); sparse kernel 20. */
 int lsm_reservoir_input_mode(const lsm_reservoir *h, int n_clips, int n_steps, int waves_per_clip);
 
+/* Host-only (no GPU, no HIP call): the ring-window table, the pair-block lists ({LDS byte offset of the target's accumulator,
+ * weight bits} per entry) and the 16-byte row records lsm_reservoir_create would build for these CSC arrays and `wpc` (4, 8, 16)
+ * waves per clip, with the two tables placed at the given (fictitious) addresses.  Call with null arrays for the sizes
+ * (band_floats, n_list_entries, pitch_bytes), then with band_out[band_floats], rem_out[2 * n_list_entries],
+ * rec_out[4 * num_neurons * wpc].  Returns the blocks per wave, 0 when the reservoir has no pair layout with that many waves,
+ * < 0 on a bad argument.  tests/test_pair_layout.py applies every row from these tables alone, on the CPU. */
+int lsm_debug_pair_layout(int num_neurons, const int32_t *csc_ptr, const int32_t *csc_post, const float *csc_w, int wpc,
+                          unsigned long long band_addr, unsigned long long rem_addr, long *band_floats, long *n_list_entries,
+                          int *pitch_bytes, float *band_out, uint32_t *rem_out, uint32_t *rec_out);
+
 /* Diagnostic builds (-DLSM_STAMP=1) only: per-phase s_memtime sums of the reservoir kernel
  * (out8: 8 counters, HOST memory); all zeros in the shipped build. */
 int lsm_debug_lif_stamps(unsigned long long *out8, int reset);

@@ -55,6 +55,8 @@ _SIGS = {
                                    C.POINTER(c_int), C.POINTER(c_int), C.POINTER(C.c_long)]),
     "lsm_reservoir_row_request_bytes": (c_int, [c_void, c_int, c_int, c_int, C.POINTER(C.c_double)]),
     "lsm_reservoir_input_mode": (c_int, [c_void, c_int, c_int, c_int]),
+    "lsm_debug_pair_layout": (c_int, [c_int, c_void, c_void, c_void, c_int, C.c_ulonglong, C.c_ulonglong,
+                                      C.POINTER(C.c_long), C.POINTER(C.c_long), C.POINTER(c_int), c_void, c_void, c_void]),
     "lsm_debug_lif_stamps": (c_int, [c_void, c_int]),
 }
 

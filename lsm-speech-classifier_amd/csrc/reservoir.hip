@@ -286,6 +286,155 @@ static bool colour_input_channels(int N, int C, const int32_t *in_tgt, int in_fa
     return true;
 }
 
+// ---- ring-row geometry and the pair-block tables: host arithmetic only (no HIP call), shared by lsm_reservoir_create and
+// lsm_debug_pair_layout, which lets a CPU test apply every row from the tables alone (tests/test_pair_layout.py) ----
+struct RingGeometry {
+    int H = 0, NQ = 0, NP = 0, wsq = 0;
+    uint32_t pitch = 0;
+    std::vector<int> a4v, nbytes;       // per row: 32-aligned first target of the window; bytes of the row that exist
+    // byte offset of synapse (j -> i) in row j, or -1 when i lies outside the stored window
+    long win_off(int j, int i) const
+    {
+        int p = i - a4v[j]; p += p < 0 ? NP : 0;
+        const long off = (long)p * 4;
+        return off < nbytes[j] ? off : -1;
+    }
+};
+
+// Window half-width H = half the mean out-degree (k/2 of a small-world graph).  Row j covers the targets from the
+// 32-aligned start of (j-H) mod N up to (j+H) mod N along the ring padded to NQ quads of 256.  False when the reservoir is
+// not ring-like enough for the format (the plain window must hold most of the synapses and be a real saving).
+static bool ring_geometry(int N, const int32_t *csc_ptr, const int32_t *csc_post, size_t nnz, RingGeometry *g)
+{
+    const int H = (int)((nnz / (size_t)N + 1) / 2);
+    const int wd = 2 * H + 1;
+    const int NQ = (N + 255) / 256;
+    size_t inside = 0;
+    for (int j = 0; j < N; ++j)
+        for (int e = csc_ptr[j]; e < csc_ptr[j + 1]; ++e) {
+            int q = csc_post[e] - (j - H);
+            q = q < 0 ? q + N : (q >= N ? q - N : q);
+            inside += q < wd;
+        }
+    if (!(H >= 1 && 2 * wd <= N && NQ >= 2 && nnz > 0 && inside * 10 >= nnz * 6)) return false;
+    // geometry per row: a4 (32-aligned first target of the window: 128 bytes), bytes that exist (up to the window's
+    // end along the padded ring of NQ*256 positions, 16-byte granules), quads the window touches
+    g->H = H; g->NQ = NQ; g->NP = NQ * 256;
+    g->a4v.assign(N, 0); g->nbytes.assign(N, 0);
+    int wsq = 0, maxb = 0;
+    for (int j = 0; j < N; ++j) {
+        int a0 = j - H; a0 += a0 < 0 ? N : 0;
+        int b0 = j + H; b0 -= b0 >= N ? N : 0;
+        const int a4 = a0 & ~31;
+        int span = b0 - a4; span += span < 0 ? g->NP : 0;
+        g->a4v[j] = a4;
+        g->nbytes[j] = ((span >> 2) + 1) * 16;
+        maxb = std::max(maxb, g->nbytes[j]);
+        wsq = std::max(wsq, (((a4 & 255) + span) >> 8) + 1);
+    }
+    g->wsq = wsq;
+    g->pitch = ((uint32_t)maxb + 127u) & ~127u;         // every row starts on a 128-byte line
+    return wsq < NQ;
+}
+
+static void ring_windows(int N, const int32_t *csc_ptr, const int32_t *csc_post, const float *csc_w, const RingGeometry &g,
+                         std::vector<float> *band)
+{
+    band->assign((size_t)N * (g.pitch / 4), 0.0f);
+    for (int j = 0; j < N; ++j)
+        for (int e = csc_ptr[j]; e < csc_ptr[j + 1]; ++e) {
+            const long off = g.win_off(j, csc_post[e]);
+            if (off >= 0) (*band)[(size_t)j * (g.pitch / 4) + (size_t)(off / 4)] = csc_w[e];
+        }
+}
+
+// Pair blocks (lif_pair.h): the windows shared out in 128-neuron blocks, wave w owning the blocks w, w+wpc, ...: the
+// residues must survive the ring's wrap (2*NQ % wpc == 0), a window must not touch more than wpc blocks, a wave at most
+// four blocks (8 neurons per lane), a (row, wave) list at most 64 entries.  Returns the blocks per wave, 0 = no layout.
+static int pair_lists(int N, int wpc, const int32_t *csc_ptr, const int32_t *csc_post, const float *csc_w,
+                      const RingGeometry &g, std::vector<uint32_t> *rptr, std::vector<uint2> *rem)
+{
+    const int NB = 2 * g.NQ;
+    int wsb = 0;
+    for (int j = 0; j < N; ++j) wsb = std::max(wsb, (((g.a4v[j] & 127) + (g.nbytes[j] / 4 - 1)) >> 7) + 1);
+    if (NB % wpc != 0 || wsb > wpc) return 0;
+    const int bl = NB / wpc;
+    if (bl < 1 || bl > 4) return 0;
+    rptr->assign((size_t)N * wpc + 1, 0u);
+    int emax = 0;
+    for (int j = 0; j < N; ++j)
+        for (int e = csc_ptr[j]; e < csc_ptr[j + 1]; ++e)
+            if (g.win_off(j, csc_post[e]) < 0)
+                emax = std::max(emax, (int)++(*rptr)[(size_t)j * wpc + lsm_lif::pair_wave_of_block(csc_post[e] >> 7, wpc) + 1]);
+    if (emax > 64) return 0;                                 // one lane per list entry
+    for (size_t q = 1; q < rptr->size(); ++q) (*rptr)[q] += (*rptr)[q - 1];
+    if ((uint64_t)rptr->back() * 8u >= (1ull << 32)) return 0;
+    rem->assign(std::max<size_t>(1, rptr->back()), make_uint2(0u, 0u));
+    std::vector<uint32_t> fill(rptr->begin(), rptr->end() - 1);
+    for (int j = 0; j < N; ++j)
+        for (int e = csc_ptr[j]; e < csc_ptr[j + 1]; ++e) {
+            const int i = csc_post[e];
+            if (g.win_off(j, i) >= 0) continue;
+            uint32_t bits;
+            std::memcpy(&bits, &csc_w[e], 4);
+            (*rem)[fill[(size_t)j * wpc + lsm_lif::pair_wave_of_block(i >> 7, wpc)]++] = make_uint2(lsm_lif::pair_acc_byte(i), bits);
+        }
+    return bl;
+}
+
+// The records carry addresses (low halves) of the window table at band_a and of the list table at rem_a.
+static void pair_records(int N, int wpc, const RingGeometry &g, const std::vector<uint32_t> &rptr, uint64_t band_a, uint64_t rem_a,
+                         std::vector<uint4> *rec)
+{
+    const int NB = 2 * g.NQ;
+    rec->resize((size_t)N * wpc);
+    for (int j = 0; j < N; ++j) {
+        const int q0 = g.a4v[j] >> 7, lead = g.a4v[j] & 127;
+        for (int w = 0; w < wpc; ++w) {
+            int ph = (w - q0) % wpc; ph += ph < 0 ? wpc : 0;
+            int gb = q0 + ph; gb -= gb >= NB ? NB : 0;
+            const size_t q = (size_t)j * wpc + w;
+            (*rec)[q] = lsm_lif::pair_record((uint32_t)(band_a + (uint64_t)j * g.pitch), (ph * 128 - lead) * 4, gb,
+                                            (uint32_t)g.nbytes[j], (uint32_t)(rem_a + (uint64_t)rptr[q] * 8u), rptr[q + 1] - rptr[q]);
+        }
+    }
+}
+
+// Host-only (no GPU, no HIP call): the ring-window table, the pair-block lists and the row records lsm_reservoir_create would
+// build for these CSC arrays and `wpc` waves per clip, with the tables placed at the given (fictitious) addresses.  Sizes first
+// (null outputs), then the arrays.  Returns the blocks per wave, 0 when the reservoir has no pair layout with that many waves,
+// < 0 on a bad argument.  tests/test_pair_layout.py applies every row from these tables alone and compares with the column.
+extern "C" __attribute__((visibility("default")))
+int lsm_debug_pair_layout(int num_neurons, const int32_t *csc_ptr, const int32_t *csc_post, const float *csc_w, int wpc,
+                          unsigned long long band_addr, unsigned long long rem_addr, long *band_floats, long *n_list_entries,
+                          int *pitch_bytes, float *band_out, uint32_t *rem_out, uint32_t *rec_out)
+{
+    LSM_REQUIRE(num_neurons >= 1 && num_neurons <= 8192 && csc_ptr && csc_post && csc_w, "lsm_debug_pair_layout: bad argument");
+    LSM_REQUIRE(wpc == 4 || wpc == 8 || wpc == 16, "lsm_debug_pair_layout: wpc must be 4, 8 or 16");
+    const int N = num_neurons;
+    RingGeometry g;
+    if (!ring_geometry(N, csc_ptr, csc_post, (size_t)csc_ptr[N], &g)) return 0;
+    std::vector<uint32_t> rptr;
+    std::vector<uint2> rem;
+    const int bl = pair_lists(N, wpc, csc_ptr, csc_post, csc_w, g, &rptr, &rem);
+    if (!bl) return 0;
+    if (band_floats) *band_floats = (long)N * (g.pitch / 4);
+    if (n_list_entries) *n_list_entries = (long)rptr.back();
+    if (pitch_bytes) *pitch_bytes = (int)g.pitch;
+    if (band_out) {
+        std::vector<float> band;
+        ring_windows(N, csc_ptr, csc_post, csc_w, g, &band);
+        std::memcpy(band_out, band.data(), band.size() * sizeof(float));
+    }
+    if (rem_out) std::memcpy(rem_out, rem.data(), (size_t)rptr.back() * sizeof(uint2));
+    if (rec_out) {
+        std::vector<uint4> rec;
+        pair_records(N, wpc, g, rptr, band_addr, rem_addr, &rec);
+        std::memcpy(rec_out, rec.data(), rec.size() * sizeof(uint4));
+    }
+    return bl;
+}
+
 extern "C" __attribute__((visibility("default")))
 int lsm_reservoir_create(lsm_reservoir **out, int num_neurons, int n_channels,
                          const int32_t *csc_ptr, const int32_t *csc_post, const float *csc_w,
@@ -429,55 +578,21 @@ int lsm_reservoir_create(lsm_reservoir **out, int num_neurons, int n_channels,
     // (ensure_dense_rows); a reservoir that auto mode serves with ring rows gets them on lsm_reservoir_set_kernel(2).
     for (const auto &v : h->var)
         if (v.wpc) h->ld = std::max(h->ld, v.sl * 64 * v.wpc);
-    // Ring rows for ring-like graphs (lif_ring.h): window half-width H = half the mean out-degree (k/2 of a
-    // small-world graph).  Row j covers the targets from the 32-aligned start of (j-H) mod N up to (j+H) mod N
-    // along the ring padded to NQ quads of 256.  Offered when the plain window holds most of the synapses and is
-    // a real saving (< half a row).
+    // Ring rows for ring-like graphs (lif_ring.h, lif_pair.h): ring_geometry / ring_windows above.
     {
-        const int H = (int)((nnz / (size_t)N + 1) / 2);
-        const int wd = 2 * H + 1;
-        const int NQ = (N + 255) / 256;
-        size_t inside = 0;
-        for (int j = 0; j < N; ++j)
-            for (int e = csc_ptr[j]; e < csc_ptr[j + 1]; ++e) {
-                int q = csc_post[e] - (j - H);
-                q = q < 0 ? q + N : (q >= N ? q - N : q);
-                inside += q < wd;
-            }
         // (the ring kernel counts a neuron's active input entries of a step in 16 bits)
         std::vector<uint32_t> fanin(N, 0u);
         uint32_t max_fanin = 0;
         for (size_t e = 0; e < (size_t)C * in_fanout; ++e) max_fanin = std::max(max_fanin, ++fanin[in_tgt[e]]);
-        if (H >= 1 && 2 * wd <= N && NQ >= 2 && nnz > 0 && inside * 10 >= nnz * 6 && max_fanin <= 65535u) {
-            // geometry per row: a4 (32-aligned first target of the window: 128 bytes), bytes that exist (up to the window's
-            // end along the padded ring of NQ*256 positions, 16-byte granules), quads the window touches
-            const int NP = NQ * 256;
-            std::vector<int> a4v(N), nbytes(N);
-            int wsq = 0, maxb = 0;
-            for (int j = 0; j < N; ++j) {
-                int a0 = j - H; a0 += a0 < 0 ? N : 0;
-                int b0 = j + H; b0 -= b0 >= N ? N : 0;
-                const int a4 = a0 & ~31;
-                int span = b0 - a4; span += span < 0 ? NP : 0;
-                a4v[j] = a4;
-                nbytes[j] = ((span >> 2) + 1) * 16;
-                maxb = std::max(maxb, nbytes[j]);
-                wsq = std::max(wsq, (((a4 & 255) + span) >> 8) + 1);
-            }
-            if (wsq < NQ) {
-                const uint32_t pitch = ((uint32_t)maxb + 127u) & ~127u;     // every row starts on a 128-byte line
-                std::vector<float> band((size_t)N * (pitch / 4), 0.0f);
-                // byte offset of synapse (j -> i) in row j, or -1 when i lies outside the stored window
-                auto win_off = [&](int j, int i) -> long {
-                    int p = i - a4v[j]; p += p < 0 ? NP : 0;
-                    const long off = (long)p * 4;
-                    return off < nbytes[j] ? off : -1;
-                };
-                for (int j = 0; j < N; ++j)
-                    for (int e = csc_ptr[j]; e < csc_ptr[j + 1]; ++e) {
-                        const long off = win_off(j, csc_post[e]);
-                        if (off >= 0) band[(size_t)j * (pitch / 4) + (size_t)(off / 4)] = csc_w[e];
-                    }
+        RingGeometry geo;
+        if (max_fanin <= 65535u && ring_geometry(N, csc_ptr, csc_post, nnz, &geo)) {
+            {
+                const int H = geo.H, NQ = geo.NQ, wsq = geo.wsq;
+                const uint32_t pitch = geo.pitch;
+                const std::vector<int> &nbytes = geo.nbytes;
+                auto win_off = [&](int j, int i) -> long { return geo.win_off(j, i); };
+                std::vector<float> band;
+                ring_windows(N, csc_ptr, csc_post, csc_w, geo, &band);
                 if ((rc = upload(&h->band, band))) { free_reservoir(h); return rc; }
                 h->band_pitch = pitch; h->band_h = H; h->band_nq = NQ; h->band_wsq = wsq;
                 for (int j = 0; j < N; ++j) h->band_bytes_sum += nbytes[j];
@@ -582,36 +697,14 @@ int lsm_reservoir_create(lsm_reservoir **out, int num_neurons, int n_channels,
                 constexpr bool no_pairs = false;
 #endif
                 const int NB = 2 * NQ;
-                int wsb = 0;
-                for (int j = 0; j < N; ++j) wsb = std::max(wsb, (((a4v[j] & 127) + (nbytes[j] / 4 - 1)) >> 7) + 1);
                 const int pwpcs[3] = {4, 8, 16};
                 for (int vi = 0; vi < 3 && !no_pairs && C <= 128; ++vi) {
                     const int wpc = pwpcs[vi];
-                    if (NB % wpc != 0 || wsb > wpc) continue;
-                    const int bl = NB / wpc;
-                    if (bl < 1 || bl > 4) continue;
+                    std::vector<uint32_t> rptr;
+                    std::vector<uint2> rem;
+                    const int bl = pair_lists(N, wpc, csc_ptr, csc_post, csc_w, geo, &rptr, &rem);
+                    if (!bl) continue;
                     const int npad = NB * 128;
-                    std::vector<uint32_t> rptr((size_t)N * wpc + 1, 0u);
-                    int emax = 0;
-                    for (int j = 0; j < N; ++j)
-                        for (int e = csc_ptr[j]; e < csc_ptr[j + 1]; ++e)
-                            if (win_off(j, csc_post[e]) < 0)
-                                emax = std::max(emax, (int)++rptr[(size_t)j * wpc +
-                                                                  lsm_lif::pair_wave_of_block(csc_post[e] >> 7, wpc) + 1]);
-                    if (emax > 64) continue;                             // one lane per list entry
-                    for (size_t q = 1; q < rptr.size(); ++q) rptr[q] += rptr[q - 1];
-                    if ((uint64_t)rptr.back() * 8u >= (1ull << 32)) continue;
-                    std::vector<uint2> rem(std::max<size_t>(1, rptr.back()));
-                    std::vector<uint32_t> fill(rptr.begin(), rptr.end() - 1);
-                    for (int j = 0; j < N; ++j)
-                        for (int e = csc_ptr[j]; e < csc_ptr[j + 1]; ++e) {
-                            const int i = csc_post[e];
-                            if (win_off(j, i) >= 0) continue;
-                            uint32_t bits;
-                            std::memcpy(&bits, &csc_w[e], 4);
-                            rem[fill[(size_t)j * wpc + lsm_lif::pair_wave_of_block(i >> 7, wpc)]++] =
-                                make_uint2(lsm_lif::pair_acc_byte(i), bits);
-                        }
                     // the records carry device addresses (low halves): upload the lists first; a table that crosses a 4 GB
                     // line (the kernel takes the high address bits from the table pointer) cannot serve this layout
                     PairVariant &v = h->pvar[vi];
@@ -623,18 +716,8 @@ int lsm_reservoir_create(lsm_reservoir **out, int num_neurons, int n_channels,
                         v.rem = nullptr;
                         continue;
                     }
-                    std::vector<uint4> rec((size_t)N * wpc);
-                    for (int j = 0; j < N; ++j) {
-                        const int q0 = a4v[j] >> 7, lead = a4v[j] & 127;
-                        for (int w = 0; w < wpc; ++w) {
-                            int ph = (w - q0) % wpc; ph += ph < 0 ? wpc : 0;
-                            int gb = q0 + ph; gb -= gb >= NB ? NB : 0;
-                            const size_t q = (size_t)j * wpc + w;
-                            rec[q] = lsm_lif::pair_record((uint32_t)(band_a + (uint64_t)j * pitch), (ph * 128 - lead) * 4, gb,
-                                                          (uint32_t)nbytes[j], (uint32_t)(rem_a + (uint64_t)rptr[q] * 8u),
-                                                          rptr[q + 1] - rptr[q]);
-                        }
-                    }
+                    std::vector<uint4> rec;
+                    pair_records(N, wpc, geo, rptr, band_a, rem_a, &rec);
                     std::vector<int> os(npad, -1);
                     for (int o = 0; o < n_out; ++o) os[out_idx[o]] = o;
                     std::vector<uint32_t> im((size_t)npad * 4, 0u);

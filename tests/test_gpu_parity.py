@@ -540,6 +540,12 @@ def test_input_maps_with_and_without_a_mask_colouring(torch_cuda, oracle_c, hub_
         for wpc in (0, 4, 8):
             total += _check_against_oracle(net, rasters, oracle_c, wpc)
     assert total > 500
+    # the pair-block ring kernel holds the same masks: coloured positions (input mode 15) or, for the 33-channel hub, natural
+    # ones and four popcounts (14)
+    net.set_kernel("ring-pairs")
+    for wpc in (4, 8):
+        assert net.plan(3, t, wpc)["input_mode"] == (14 if hub_channels > 32 else 15)
+        assert _check_against_oracle(net, rasters, oracle_c, wpc) > 1
 
 
 @pytest.mark.parametrize("n,k,c,t", [(1024, 120, 40, 120), (2048, 300, 96, 100), (4096, 300, 200, 80),
