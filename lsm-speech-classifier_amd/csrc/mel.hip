@@ -13,6 +13,10 @@
 
 namespace {
 
+#ifndef LSM_MEL_ABLATE
+#define LSM_MEL_ABLATE 0    // diagnostic builds only (WRONG results): 1 = no FFT passes, 2 = no mel projection (every filter gets
+#endif                      // its first bin), 4 = no unpack / power (profiles/r05_mel_power_parts.txt: where the kernel's time goes)
+
 constexpr int NFFT = 2048;
 constexpr int N2 = NFFT / 2;                 // the real frame is transformed as N2 complex points
 constexpr int NBINS = NFFT / 2 + 1;
@@ -64,7 +68,7 @@ __device__ __forceinline__ void mel_power_body(const MelArgs &a, double2 (*buf)[
     __syncthreads();
     int cur = 0;
 #pragma unroll
-    for (int p = 1; p < N2; p <<= 2) {          // p = 1, 4, 16, 64, 256
+    for (int p = 1; p < ((LSM_MEL_ABLATE & 1) ? 1 : N2); p <<= 2) {          // p = 1, 4, 16, 64, 256
         const double2 *in = buf[cur];
         double2 *out = buf[cur ^ 1];
         const int k = tid & (p - 1);
@@ -86,7 +90,7 @@ __device__ __forceinline__ void mel_power_body(const MelArgs &a, double2 (*buf)[
         __syncthreads();
     }
     const double2 *Z = buf[cur];
-    for (int f = tid; f < NBINS; f += 256) {
+    for (int f = tid; f < ((LSM_MEL_ABLATE & 4) ? 0 : NBINS); f += 256) {
         const double2 zk = Z[f & (N2 - 1)];
         const double2 zr = Z[(N2 - f) & (N2 - 1)];
         const double2 E = make_double2(0.5 * (zk.x + zr.x), 0.5 * (zk.y - zr.y));    // (Zk + conj Zr)/2
@@ -105,7 +109,7 @@ __device__ __forceinline__ void mel_power_body(const MelArgs &a, double2 (*buf)[
         if (m < n_mels) {
             const float *row = basis + (size_t)m * NBINS;
             const int h = hi[m];
-            for (int f = lo[m] + q; f < h; f += 4) acc += row[f] * pw[f];
+            for (int f = lo[m] + q; f < ((LSM_MEL_ABLATE & 2) ? lo[m] + 1 : h); f += 4) acc += row[f] * pw[f];
         }
         acc += __shfl_xor(acc, 1);
         acc += __shfl_xor(acc, 2);
