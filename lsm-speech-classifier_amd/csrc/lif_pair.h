@@ -40,7 +40,8 @@ namespace lsm_lif {
 #endif
 #ifndef LSM_PAIR_ABLATE
 #define LSM_PAIR_ABLATE 0   // diagnostic builds only (WRONG results): 1 = no window loads, 2 = no accumulator read-modify-write,
-#endif                      // 8 = no list loads, 32 = no feature updates
+#endif                      // 8 = no list loads, 32 = no feature updates, 64 = no accumulator reads, 128 = the window piece summed in a
+                            // register and the list entry added by ds_add_f32 (no LDS round trip between rows; no block switches)
 
 #ifndef LSM_PAIR_PHASES
 #define LSM_PAIR_PHASES 0   // diagnostic builds only: every wave sums the core-clock cycles of its step phases and writes them OVER
@@ -458,9 +459,14 @@ void lif_pair_kernel(const PairArgs a)
             // such lane rewrites with the same value, old + 0 -- same-address lanes of one LDS instruction do not conflict)
 #define LSM_PAIR_READ(p)                                                                        \
     {                                                                                           \
-        old[(p) & 1] = LSM_PAIR_LDS_F2(wa[p] + PAIR_DUMP_BYTES);                                \
-        if (LSM_PAIR_OWN_DUMP) re[p].x = max(re[p].x, lane8 >> 1);                              \
-        oldl[(p) & 1] = LSM_PAIR_LDS_F1(re[p].x);                                               \
+        if (LSM_PAIR_ABLATE & (64 | 128)) {                                                     \
+            old[(p) & 1] = (pair_f2){0.0f, 0.0f};                                               \
+            oldl[(p) & 1] = 0.0f;                                                               \
+        } else {                                                                                \
+            old[(p) & 1] = LSM_PAIR_LDS_F2(wa[p] + PAIR_DUMP_BYTES);                            \
+            if (LSM_PAIR_OWN_DUMP) re[p].x = max(re[p].x, lane8 >> 1);                          \
+            oldl[(p) & 1] = LSM_PAIR_LDS_F1(re[p].x);                                           \
+        }                                                                                       \
         __builtin_amdgcn_sched_barrier(0);                                                      \
     }
             // APPLY(p): add row p and write back -- the window pair first, the list word after it (a list target may sit in
@@ -469,7 +475,10 @@ void lif_pair_kernel(const PairArgs a)
 #define LSM_PAIR_APPLY(p)                                                                       \
     {                                                                                           \
         LSM_PAIR_DUMMY_USE(p)                                                                   \
-        if (!(LSM_PAIR_ABLATE & 2)) {                                                           \
+        if (LSM_PAIR_ABLATE & 128) {                                                            \
+            abl_cur_ = abl_cur_ + wv[p];                                                        \
+            asm volatile("ds_add_f32 %0, %1" : : "v"(max(re[p].x, lane8 >> 1)), "v"(__uint_as_float(re[p].y)) : "memory"); \
+        } else if (!(LSM_PAIR_ABLATE & 2)) {                                                    \
             /* the list sum first: its read was issued last, so ONE wait covers both reads */   \
             float newl = oldl[(p) & 1] + __uint_as_float(re[p].y);                              \
             asm volatile("" : "+v"(newl));                                                      \
@@ -481,6 +490,7 @@ void lif_pair_kernel(const PairArgs a)
         __builtin_amdgcn_sched_barrier(0);                                                      \
     }
             static_assert(P % 2 == 0, "the look-ahead sets alternate by the row's parity");
+            pair_f2 abl_cur_ = {0.0f, 0.0f};
 #pragma unroll
             for (int p = 0; p < P; ++p) {
                 LSM_PAIR_SEL(p)
@@ -507,6 +517,7 @@ void lif_pair_kernel(const PairArgs a)
                     if (p > 0) LSM_PAIR_READ(p)
                     LSM_PAIR_APPLY(p)
                 }
+            if (LSM_PAIR_ABLATE & 128) LSM_PAIR_LDS_F2(lane8 + PAIR_DUMP_BYTES) = abl_cur_;
 #undef LSM_PAIR_SEL
 #undef LSM_PAIR_ISSUE
 #undef LSM_PAIR_DUMMY_WORK
