@@ -35,13 +35,16 @@ namespace lsm_lif {
 #define LSM_PAIR_P 4        // rows in flight (5 registers each; same-box: 4 rows 4.49 ms, 6 rows 4.62, 8 rows 4.89 at cfg4 -- every
                             // chunk ends with P requested rows that do not exist: profiles/r05_pair_rows_in_flight.txt)
 #endif
+#ifndef LSM_PAIR_EXACT
+#define LSM_PAIR_EXACT 1    // 1: the row loop requests exactly the rows of a chunk; 0: whole turns of P (round 5's first form)
+#endif
 #ifndef LSM_PAIR_PRIO
 #define LSM_PAIR_PRIO 1     // wave priority of the step loop (as lif_ring.h: profiles/r04_ring_priority.txt)
 #endif
 #ifndef LSM_PAIR_ABLATE
 #define LSM_PAIR_ABLATE 0   // diagnostic builds only (WRONG results): 1 = no window loads, 2 = no accumulator read-modify-write,
 #endif                      // 8 = no list loads, 32 = no feature updates, 64 = no accumulator reads, 128 = the window piece summed in a
-                            // register and the list entry added by ds_add_f32 (no LDS round trip between rows; no block switches)
+                            // register (no block switches), 256 = the list entries summed in a register (profiles/r05_pair_rmw_ablation.txt)
 
 #ifndef LSM_PAIR_PHASES
 #define LSM_PAIR_PHASES 0   // diagnostic builds only: every wave sums the core-clock cycles of its step phases and writes them OVER
@@ -459,14 +462,11 @@ void lif_pair_kernel(const PairArgs a)
             // such lane rewrites with the same value, old + 0 -- same-address lanes of one LDS instruction do not conflict)
 #define LSM_PAIR_READ(p)                                                                        \
     {                                                                                           \
-        if (LSM_PAIR_ABLATE & (64 | 128)) {                                                     \
-            old[(p) & 1] = (pair_f2){0.0f, 0.0f};                                               \
-            oldl[(p) & 1] = 0.0f;                                                               \
-        } else {                                                                                \
-            old[(p) & 1] = LSM_PAIR_LDS_F2(wa[p] + PAIR_DUMP_BYTES);                            \
-            if (LSM_PAIR_OWN_DUMP) re[p].x = max(re[p].x, lane8 >> 1);                          \
-            oldl[(p) & 1] = LSM_PAIR_LDS_F1(re[p].x);                                           \
-        }                                                                                       \
+        if (LSM_PAIR_ABLATE & (64 | 128)) old[(p) & 1] = (pair_f2){0.0f, 0.0f};                 \
+        else old[(p) & 1] = LSM_PAIR_LDS_F2(wa[p] + PAIR_DUMP_BYTES);                           \
+        if (LSM_PAIR_OWN_DUMP) re[p].x = max(re[p].x, lane8 >> 1);                              \
+        if (LSM_PAIR_ABLATE & (64 | 256)) oldl[(p) & 1] = 0.0f;                                 \
+        else oldl[(p) & 1] = LSM_PAIR_LDS_F1(re[p].x);                                          \
         __builtin_amdgcn_sched_barrier(0);                                                      \
     }
             // APPLY(p): add row p and write back -- the window pair first, the list word after it (a list target may sit in
@@ -475,22 +475,79 @@ void lif_pair_kernel(const PairArgs a)
 #define LSM_PAIR_APPLY(p)                                                                       \
     {                                                                                           \
         LSM_PAIR_DUMMY_USE(p)                                                                   \
-        if (LSM_PAIR_ABLATE & 128) {                                                            \
-            abl_cur_ = abl_cur_ + wv[p];                                                        \
-            asm volatile("ds_add_f32 %0, %1" : : "v"(max(re[p].x, lane8 >> 1)), "v"(__uint_as_float(re[p].y)) : "memory"); \
-        } else if (!(LSM_PAIR_ABLATE & 2)) {                                                    \
+        if (!(LSM_PAIR_ABLATE & 2)) {                                                           \
             /* the list sum first: its read was issued last, so ONE wait covers both reads */   \
             float newl = oldl[(p) & 1] + __uint_as_float(re[p].y);                              \
             asm volatile("" : "+v"(newl));                                                      \
-            LSM_PAIR_LDS_F2(wa[p] + PAIR_DUMP_BYTES) = old[(p) & 1] + wv[p];                    \
+            if (LSM_PAIR_ABLATE & 128) abl_cur_ = abl_cur_ + wv[p];                             \
+            else LSM_PAIR_LDS_F2(wa[p] + PAIR_DUMP_BYTES) = old[(p) & 1] + wv[p];               \
             asm volatile("" ::: "memory");                                                      \
-            LSM_PAIR_LDS_F1(re[p].x) = newl;                                                    \
+            if (LSM_PAIR_ABLATE & 256) abl_l_ += newl;                                          \
+            else LSM_PAIR_LDS_F1(re[p].x) = newl;                                               \
             asm volatile("" ::: "memory");                                                      \
         }                                                                                       \
         __builtin_amdgcn_sched_barrier(0);                                                      \
     }
             static_assert(P % 2 == 0, "the look-ahead sets alternate by the row's parity");
-            pair_f2 abl_cur_ = {0.0f, 0.0f};
+            pair_f2 abl_cur_ = {0.0f, 0.0f};       // LSM_PAIR_ABLATE & 128 / 256 only
+            float abl_l_ = 0.0f;
+#if LSM_PAIR_EXACT
+            // Exactly the chunk's n rows are requested (a buffer load holds the texture-address path about 11 cycles whether
+            // or not its descriptor has bytes: profiles/r05_residency_ablation.txt).  n >= P: P rows requested, whole turns
+            // of P rows while the P rows requested in a turn all exist, one last turn that requests the n % P rows left, then
+            // those rows on their own.  n < P: the n rows requested together, then applied.
+            if (n >= P) {
+#pragma unroll
+                for (int p = 0; p < P; ++p) {
+                    LSM_PAIR_SEL(p)
+                    LSM_PAIR_ISSUE(p)
+                }
+                LSM_PAIR_MARK(2)       // first P rows requested
+                LSM_PAIR_READ(0)
+                int m = 0;
+                for (; m + 2 * P <= n; m += P) {
+#pragma unroll
+                    for (int p = 0; p < P; ++p) {
+                        LSM_PAIR_SEL(m + p + P)
+                        LSM_PAIR_APPLY(p)
+                        LSM_PAIR_READ((p + 1) % P)
+                        LSM_PAIR_ISSUE(p)
+                    }
+                }
+                const int rest = n - m - P;         // 0 .. P-1 rows not yet requested (wave-uniform)
+#pragma unroll
+                for (int p = 0; p < P; ++p) {
+                    if (p < rest) LSM_PAIR_SEL(m + p + P)
+                    LSM_PAIR_APPLY(p)
+                    if (p + 1 < P) {
+                        LSM_PAIR_READ(p + 1)
+                    } else if (rest > 0) {
+                        LSM_PAIR_READ(0)
+                    }
+                    if (p < rest) LSM_PAIR_ISSUE(p)
+                }
+#pragma unroll
+                for (int p = 0; p < P - 1; ++p)
+                    if (p < rest) {
+                        if (p > 0) LSM_PAIR_READ(p)
+                        LSM_PAIR_APPLY(p)
+                    }
+            } else {
+#pragma unroll
+                for (int p = 0; p < P - 1; ++p)
+                    if (p < n) {
+                        LSM_PAIR_SEL(p)
+                        LSM_PAIR_ISSUE(p)
+                    }
+                LSM_PAIR_MARK(2)
+#pragma unroll
+                for (int p = 0; p < P - 1; ++p)
+                    if (p < n) {
+                        LSM_PAIR_READ(p)
+                        LSM_PAIR_APPLY(p)
+                    }
+            }
+#else
 #pragma unroll
             for (int p = 0; p < P; ++p) {
                 LSM_PAIR_SEL(p)
@@ -517,7 +574,8 @@ void lif_pair_kernel(const PairArgs a)
                     if (p > 0) LSM_PAIR_READ(p)
                     LSM_PAIR_APPLY(p)
                 }
-            if (LSM_PAIR_ABLATE & 128) LSM_PAIR_LDS_F2(lane8 + PAIR_DUMP_BYTES) = abl_cur_;
+#endif
+            if (LSM_PAIR_ABLATE & (128 | 256)) LSM_PAIR_LDS_F2(lane8 + PAIR_DUMP_BYTES) = abl_cur_ + (pair_f2){abl_l_, 0.0f};
 #undef LSM_PAIR_SEL
 #undef LSM_PAIR_ISSUE
 #undef LSM_PAIR_DUMMY_WORK
