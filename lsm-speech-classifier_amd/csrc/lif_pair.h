@@ -32,12 +32,13 @@
 namespace lsm_lif {
 
 #ifndef LSM_PAIR_P
-#define LSM_PAIR_P 4        // rows in flight (5 registers each; same-box: 4 rows 4.49 ms, 6 rows 4.62, 8 rows 4.89 at cfg4 -- every
-                            // chunk ends with P requested rows that do not exist: profiles/r05_pair_rows_in_flight.txt)
+#define LSM_PAIR_P 4        // rows in flight (5 registers each; 6 rows: the lone launch 1.5 % faster, the whole path 3.5 % slower:
+                            // profiles/r05_pair_rows_in_flight.txt)
 #endif
-#ifndef LSM_PAIR_EXACT
-#define LSM_PAIR_EXACT 1    // 1: the row loop requests exactly the rows of a chunk; 0: whole turns of P (round 5's first form)
-#endif
+#ifndef LSM_PAIR_PRE
+#define LSM_PAIR_PRE 0      // where a step's input counts and leak terms (they do not depend on the recurrent sums) are computed: 0 = in the
+#endif                      // update; 1 = while the first chunk's row records are fetched; 2 = while its first rows are fetched (both 1-2 %
+                            // SLOWER at cfg4: the other waves of the CU fill those waits already; profiles/r05_pair_rows_in_flight.txt)
 #ifndef LSM_PAIR_PRIO
 #define LSM_PAIR_PRIO 1     // wave priority of the step loop (as lif_ring.h: profiles/r04_ring_priority.txt)
 #endif
@@ -128,7 +129,7 @@ typedef __attribute__((address_space(3))) float pair_lds_f1;
 
 constexpr int PAIR_DUMP_BYTES = 256;                // LDS bytes 0..255: word 0 is where a lane without a list entry adds its zero
 constexpr int PAIR_MAX_BLOCKS = 64;                 // 8192 neurons
-constexpr int PAIR_CHUNK = 48;                      // rows per chunk: with at most 8 rows in flight no row index passes lane 63
+constexpr int PAIR_CHUNK = 64;                      // rows per chunk: lane m holds the record of the chunk's row m
 constexpr int PAIR_WCNT_WORDS = 2 * PAIR_MAX_BLOCKS + 8;
 
 // LDS byte offset (from the start of LDS) of neuron i's float32 accumulator
@@ -202,6 +203,20 @@ __device__ __forceinline__ float pair_feature_value(int key, int n, int bursts, 
     return (float)val;
 }
 
+// spiking input channels of one neuron in this step: its channel masks against the step's input bit row
+template <int INMASK>
+__device__ __forceinline__ uint32_t pair_input_count(const uint32_t (&im)[4], const uint32_t (&rowbits)[4])
+{
+    if (INMASK == 2) {
+        // disjoint by construction of the bit positions: one popcount of the union (lif_dense.h, INMODE 3)
+        uint32_t u = im[0] & rowbits[0];
+#pragma unroll
+        for (int k = 1; k < 4; ++k) asm("v_and_or_b32 %0, %1, %2, %0" : "+v"(u) : "v"(im[k]), "v"(rowbits[k]));
+        return __popc(u);
+    }
+    return __popc(im[0] & rowbits[0]) + __popc(im[1] & rowbits[1]) + __popc(im[2] & rowbits[2]) + __popc(im[3] & rowbits[3]);
+}
+
 // BL: blocks (128 neurons, 2 per lane) per wave; WPC: waves per clip; INMASK: 1 = natural bit positions of the input
 // channels, 2 = coloured positions (lif_dense.h, INMODE 3).
 // LEAKV: a leak coefficient per neuron in registers (the reference's --leak-variance-divisor, extract_lsm_features.py:174,
@@ -218,7 +233,7 @@ void lif_pair_kernel(const PairArgs a)
     constexpr int CH = PAIR_CHUNK;
     constexpr uint32_t RSRC_FLAGS = 0x00020000u;    // raw dword buffer, gfx9 family
     static_assert(NBP <= PAIR_MAX_BLOCKS, "at most 8192 neurons");
-    static_assert(P >= 2 && P <= 8 && CH % P == 0, "rows in flight");
+    static_assert(P >= 2 && P <= 8 && CH <= 64, "rows in flight; a chunk's records live in the 64 lanes");
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint32_t *marks = reinterpret_cast<uint32_t *>(smem + PAIR_DUMP_BYTES + NPAD * 4);    // 64 words per wave
@@ -332,6 +347,27 @@ void lif_pair_kernel(const PairArgs a)
     last_ = __builtin_amdgcn_s_memtime();
 #endif
 
+    // The part of a step's update that does not wait for the recurrent sums -- the count of spiking input channels of every
+    // neuron and the leak d = v - lambda * v -- is computed while the step's first loads are in the air (LSM_PAIR_PRE); the
+    // update then forms sum + w_in * count and d + that: the same operations in the same order (SPEC.md 3).
+    uint32_t npk[(LSM_PAIR_PRE && !LSM_PAIR_LEAN) ? (SL + 3) / 4 : 1];     // input counts (<= 128 channels), a byte per neuron
+#define LSM_PAIR_PRE_UPDATE                                                                             \
+    {                                                                                                   \
+        uint32_t rowbits[4];                                    /* this step's input bit row (wave-uniform) */ \
+        if (CW == 4) {                                                                                  \
+            const uint4 q4 = *reinterpret_cast<const uint4 *>(bits + t * 4);                            \
+            rowbits[0] = q4.x; rowbits[1] = q4.y; rowbits[2] = q4.z; rowbits[3] = q4.w;                 \
+        } else {                                                                                        \
+            _Pragma("unroll") for (int k = 0; k < 4; ++k) rowbits[k] = k < CW ? bits[t * CW + k] : 0u;  \
+        }                                                                                               \
+        _Pragma("unroll") for (int r = 0; r < SL; ++r) {                                                \
+            const uint32_t nn_ = pair_input_count<INMASK>(im[r], rowbits);                              \
+            npk[r >> 2] = (r & 3) ? (npk[r >> 2] | (nn_ << (8 * (r & 3)))) : nn_;                       \
+            const float m_ = (LEAKV ? lam[r] : lam_u) * v[r];                                           \
+            v[r] = v[r] - m_;                                                                           \
+        }                                                                                               \
+    }
+
     if (LSM_PAIR_PRIO) __builtin_amdgcn_s_setprio(LSM_PAIR_PRIO);
     for (int t = 0; t < T; ++t) {
         const int cur = t & 1, prv = cur ^ 1;
@@ -369,6 +405,7 @@ void lif_pair_kernel(const PairArgs a)
             // no scalar arithmetic (an extra scalar instruction per row costs the launch five times what a vector one does:
             // profiles/r05_ring_issue_ports.txt).
             const uint4 rc = my_rec[(size_t)jl * WPC];
+            if (LSM_PAIR_PRE == 1 && !LSM_PAIR_LEAN && l0 == 0) LSM_PAIR_PRE_UPDATE
             const uint32_t rx = rc.x, rw = rc.w;
             const uint32_t r_so = (uint32_t)(int)(int16_t)(rc.y & 0xFFFFu);        // my block's byte offset in the row (signed)
             const uint32_t r_lo = rc.y >> 16;                                      // LDS offset of its accumulators
@@ -491,7 +528,6 @@ void lif_pair_kernel(const PairArgs a)
             static_assert(P % 2 == 0, "the look-ahead sets alternate by the row's parity");
             pair_f2 abl_cur_ = {0.0f, 0.0f};       // LSM_PAIR_ABLATE & 128 / 256 only
             float abl_l_ = 0.0f;
-#if LSM_PAIR_EXACT
             // Exactly the chunk's n rows are requested (a buffer load holds the texture-address path about 11 cycles whether
             // or not its descriptor has bytes: profiles/r05_residency_ablation.txt).  n >= P: P rows requested, whole turns
             // of P rows while the P rows requested in a turn all exist, one last turn that requests the n % P rows left, then
@@ -503,6 +539,7 @@ void lif_pair_kernel(const PairArgs a)
                     LSM_PAIR_ISSUE(p)
                 }
                 LSM_PAIR_MARK(2)       // first P rows requested
+                if (LSM_PAIR_PRE == 2 && !LSM_PAIR_LEAN && l0 == 0) LSM_PAIR_PRE_UPDATE
                 LSM_PAIR_READ(0)
                 int m = 0;
                 for (; m + 2 * P <= n; m += P) {
@@ -540,6 +577,7 @@ void lif_pair_kernel(const PairArgs a)
                         LSM_PAIR_ISSUE(p)
                     }
                 LSM_PAIR_MARK(2)
+                if (LSM_PAIR_PRE == 2 && !LSM_PAIR_LEAN && l0 == 0) LSM_PAIR_PRE_UPDATE
 #pragma unroll
                 for (int p = 0; p < P - 1; ++p)
                     if (p < n) {
@@ -547,34 +585,6 @@ void lif_pair_kernel(const PairArgs a)
                         LSM_PAIR_APPLY(p)
                     }
             }
-#else
-#pragma unroll
-            for (int p = 0; p < P; ++p) {
-                LSM_PAIR_SEL(p)
-                LSM_PAIR_ISSUE(p)
-            }
-            LSM_PAIR_MARK(2)           // first P rows requested
-            LSM_PAIR_READ(0)
-            // whole groups of P rows, then the chunk's last n % P rows on their own (a clip with 5 rows in a step applies 5,
-            // not 8; the loads requested for rows past the end are records with zero bytes: no traffic, nobody waits)
-            int m = 0;
-            for (; m + P <= n; m += P) {
-#pragma unroll
-                for (int p = 0; p < P; ++p) {
-                    LSM_PAIR_SEL(m + p + P)
-                    LSM_PAIR_APPLY(p)
-                    LSM_PAIR_READ((p + 1) % P)
-                    LSM_PAIR_ISSUE(p)
-                }
-            }
-            const int rest = n - m;
-#pragma unroll
-            for (int p = 0; p < P - 1; ++p)
-                if (p < rest) {                 // wave-uniform
-                    if (p > 0) LSM_PAIR_READ(p)
-                    LSM_PAIR_APPLY(p)
-                }
-#endif
             if (LSM_PAIR_ABLATE & (128 | 256)) LSM_PAIR_LDS_F2(lane8 + PAIR_DUMP_BYTES) = abl_cur_ + (pair_f2){abl_l_, 0.0f};
 #undef LSM_PAIR_SEL
 #undef LSM_PAIR_ISSUE
@@ -586,6 +596,9 @@ void lif_pair_kernel(const PairArgs a)
             LSM_PAIR_MARK(3)           // rows applied (waits for the row loads included)
         }
         wave_lds_fence();
+#if LSM_PAIR_PRE && !LSM_PAIR_LEAN
+        if (total == 0u) LSM_PAIR_PRE_UPDATE                    // a step without rows
+#else
         uint32_t rowbits[4];                                    // this step's input bit row (wave-uniform)
         if (CW == 4) {
             const uint4 q4 = *reinterpret_cast<const uint4 *>(bits + t * 4);
@@ -594,6 +607,7 @@ void lif_pair_kernel(const PairArgs a)
 #pragma unroll
             for (int k = 0; k < 4; ++k) rowbits[k] = k < CW ? bits[t * CW + k] : 0u;
         }
+#endif
 
         // ---- neuron update, block by block: leak/integrate/threshold by select, then (only if a neuron of the
         //      block fired) its entries of the block's spike list and the feature accumulators ----
@@ -614,24 +628,16 @@ void lif_pair_kernel(const PairArgs a)
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
                 const int r = 2 * q + h;
-                uint32_t nn;
-                if (LSM_PAIR_LEAN) {
-                    nn = 0u;
-                } else if (INMASK == 2) {
-                    // disjoint by construction of the bit positions: one popcount of the union (lif_dense.h, INMODE 3)
-                    uint32_t u = im[r][0] & rowbits[0];
-#pragma unroll
-                    for (int k = 1; k < 4; ++k)
-                        asm("v_and_or_b32 %0, %1, %2, %0" : "+v"(u) : "v"(im[r][k]), "v"(rowbits[k]));
-                    nn = __popc(u);
-                } else {
-                    nn = __popc(im[r][0] & rowbits[0]) + __popc(im[r][1] & rowbits[1]) +
-                         __popc(im[r][2] & rowbits[2]) + __popc(im[r][3] & rowbits[3]);
-                }
+#if LSM_PAIR_PRE && !LSM_PAIR_LEAN
+                ci[h] = ci[h] + w_in * (float)((npk[r >> 2] >> (8 * (r & 3))) & 0xFFu);    // SPEC.md §3: input term after the recurrent sum
+                const float vn = v[r] + ci[h];             // v[r] holds d = v - lambda * v since LSM_PAIR_PRE_UPDATE
+#else
+                const uint32_t nn = LSM_PAIR_LEAN ? 0u : pair_input_count<INMASK>(im[r], rowbits);
                 ci[h] = ci[h] + w_in * (float)nn;          // SPEC.md §3: input term after the recurrent sum
                 const float m = (LEAKV ? lam[r] : lam_u) * v[r];
                 const float d = v[r] - m;
                 const float vn = d + ci[h];
+#endif
 #if LSM_PAIR_REPLAY
                 const unsigned long long held = LSM_PAIR_LEAN ? 0ull : __builtin_amdgcn_uicmp(oref[r], 0x10000u, 35);
                 const unsigned long long ge = __builtin_amdgcn_fcmpf(vn, theta, 3 /* ordered >= */);
