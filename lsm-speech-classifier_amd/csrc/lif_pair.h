@@ -14,13 +14,15 @@
 //     against 17 for a quad, none of them on zeros);
 //   * everything a wave needs for row j is ONE 16-byte record built by the host, rec[j*WPC + w] = {byte offset of the
 //     row's address, my block's offset in the row | its accumulators' LDS offset, bytes that exist | bytes of
-//     my list, my list's address}: the chunk set-up is one 16-byte load per lane (= per row), and a row is four
-//     v_readlane + eight scalar instructions (the quad kernel derived all of it from j, per row, on the scalar unit);
-//     rows past the chunk's end hold a record with zero bytes: no `live` masks, no guards;
+//     my list, my list's address}: the chunk set-up is one 16-byte load per lane (= per row), and a row is six
+//     v_readlane + two scalar instructions (the quad kernel derived all of it from j, per row, on the scalar unit);
 //   * the merged order of a step's spikes (32 block lists instead of 16 quad lists) comes from two DPP scans and one
 //     pass through a 64-word LDS scratch instead of a compare chain over the blocks;
-//   * half the registers per row in flight (8-byte window pieces), so six rows are in flight where the quad kernel
-//     had four.
+//   * chunks of 64 rows, four in flight, and exactly the chunk's rows are requested: a buffer load whose descriptor
+//     has no bytes still holds the texture-address path ~11 cycles (profiles/r05_residency_ablation.txt,
+//     r05_pair_rows_in_flight.txt).
+// What bounds it (profiles/r05_pair_rmw_ablation.txt): waiting for the rows' data at the start of every step and the
+// address-path time of every request -- not the accumulator read-modify-write through LDS, not residency.
 // Arithmetic, order of the float32 additions (rows ascending, a target gets a row's weight from the window or from
 // the list, never both, the other term is +0.0) and results are those of lif_ring.h: bit-identical to the oracle.
 // The kernel exists for the input drive counted from per-neuron channel masks (C <= 128: the reference's 128 filters), with
