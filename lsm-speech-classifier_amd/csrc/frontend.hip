@@ -584,8 +584,8 @@ int launch_spec_to_spikes(const T *db, int n_clips, int n_filters, int ncols, in
     a.time_bins = time_bins; a.apply_floor = apply_floor; a.n_thr = n_thr;
     a.redundancy = redundancy; a.raster = raster; a.norm_out = norm_out;
     for (int q = 0; q < MAX_THR; ++q) { a.on[q] = q < n_thr ? thr_on[q] : (T)0; a.off[q] = q < n_thr ? thr_off[q] : (T)0; }
-    const size_t lds = 64 + (size_t)n_filters * (((size_t)time_bins * n_thr + 31) / 32) * 4;
-    LSM_REQUIRE(lds <= 160 * 1024, "raster stage of %zu bytes exceeds one CU's LDS", lds);
+    const size_t lds = lsm_fe::spikes_lds_bytes(time_bins, n_thr);
+    LSM_REQUIRE(lds <= 160 * 1024, "latch bit rows of %zu bytes (time_bins x thresholds) exceed one CU's LDS", lds);
     auto fn = spec_to_spikes_kernel<T>;
     if (lds > 64 * 1024) lsm_allow_big_lds(reinterpret_cast<const void *>(fn));
     hipLaunchKernelGGL(fn, dim3(n_clips), dim3(256), lds, (hipStream_t)stream, a);

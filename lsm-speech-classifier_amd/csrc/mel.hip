@@ -391,10 +391,11 @@ LSM_API int lsm_mel_spikes_f32(const float *audio, int n_clips, int n_samples, i
     const int row_bytes = time_bins * n_thr;
     LSM_REQUIRE((row_bytes & 3) != 0 || ((uintptr_t)raster & 3u) == 0,
                 "the raster must be 4-byte aligned when a row is a multiple of 4 bytes");
-    // the finishing workgroup stages the clip's raster bit-packed in the waves' point buffers (32 KB of them)
-    const size_t stage = 64 + (size_t)n_mels * (((size_t)row_bytes + 31) / 32) * 4;
-    if (stage > 32768) {
-        lsm_set_error("mel_spikes: a raster stage of %zu bytes exceeds the kernel's 32 KB; use the split entry points", stage);
+    // the finishing workgroup keeps its latch bit rows in the waves' point buffers
+    const size_t stage = lsm_fe::spikes_lds_bytes(time_bins, n_thr);
+    if (stage > 4 * sizeof(double2) * ZPAD) {
+        lsm_set_error("mel_spikes: latch bit rows of %zu bytes exceed the kernel's %zu; use the split entry points", stage,
+                      4 * sizeof(double2) * ZPAD);
         return LSM_ERR_UNSUPPORTED;
     }
     unsigned char *ws = static_cast<unsigned char *>(workspace);

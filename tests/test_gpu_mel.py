@@ -129,17 +129,23 @@ def test_one_launch_mel_front_end_equals_the_three_launch_route(n_mels, redundan
         fe.encode(dev, fused=True, workspace=torch.zeros(16, dtype=torch.uint8, device="cuda"))
 
 
-def test_mel_filterbanks_too_wide_for_one_launch_take_the_split_route(monkeypatch):
+def test_mel_shapes_too_long_for_one_launch_take_the_split_route(monkeypatch):
+    """The one-launch kernel's finishing workgroup keeps its latch bit rows (64 rows x thresholds x time-bin words, twice) in
+    the 68 KB of its waves' point buffers: 1200 time bins x 4 thresholds do not fit, any number of filters does."""
     import torch
     from lsm_speech_classifier_amd import frontend, synth
     monkeypatch.setenv("LSM_MEL_ONE_LAUNCH", "1")
-    fe = frontend.SpikeFrontEnd(700, "mel")
-    assert not fe.will_fuse()                               # even when asked for: the raster stage does not fit
     audio = synth.class_chirps([0, 4], seed=5)
+    fe = frontend.SpikeFrontEnd(24, "mel", time_bins=1200)
+    assert not fe.will_fuse()                               # even when asked for
     r = fe.encode(audio)                                    # split route, silently
-    assert r.shape == (2, 700, 400) and r.any()
+    assert r.shape == (2, 24, 4800) and r.any()
     with pytest.raises(ValueError):
         fe.encode(audio, fused=True)
+    wide = frontend.SpikeFrontEnd(700, "mel")
+    assert wide.will_fuse()
+    r1, r2 = wide.encode(audio), wide.encode(audio, fused=False)
+    assert r1.shape == (2, 700, 400) and r1.any() and torch.equal(r1, r2)
 
 
 @pytest.mark.parametrize("one_launch", [True, False])

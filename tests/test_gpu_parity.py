@@ -132,6 +132,32 @@ def test_frontend_against_numpy_scipy_restatement(torch_cuda):
         np.testing.assert_array_equal(raster[b].cpu().numpy(), r)
 
 
+@pytest.mark.parametrize("gap", [0.05, 0.0, -0.2])
+@pytest.mark.parametrize("n_filters,ncols,time_bins,n_thr,redundancy", [(5, 98, 100, 4, 1), (70, 101, 100, 4, 2), (3, 130, 130, 3, 1),
+                                                                         (130, 33, 70, 8, 1), (2, 64, 31, 1, 3)])
+def test_spikes_from_db_over_shapes_gaps_and_thresholds(torch_cuda, gap, n_filters, ncols, time_bins, n_thr, redundancy):
+    """lsm_spec_to_spikes_* (csrc/spikes_body.h: comparison bits by ballot, the latch of 32 time bins as one addition) against
+    the restated reference: row groups past 64 filters, rows of more and of less than 64 bins, no resize, up to 8 thresholds,
+    redundancy, and a NEGATIVE gap -- an off-bound above its on-bound, where a value between the two flips the latch
+    (create_dataset.py:88-96 takes rising and falling from the latch before the update)."""
+    import torch
+    from lsm_speech_classifier_amd import frontend
+    from oracle import ref_numpy as O
+    rng = np.random.default_rng(100 * n_filters + ncols + n_thr)
+    thr = sorted(rng.uniform(0.15, 0.95, n_thr).tolist(), reverse=True)
+    db = (rng.standard_normal((3, n_filters, ncols)).cumsum(axis=2) * 4.0 - 30.0)
+    db[2, :, ncols // 2:] = db[2, :, ncols // 2:][:, ::-1] * 0.5            # more threshold crossings
+    fe = frontend.SpikeFrontEnd(n_filters, "gammatone", redundancy=redundancy, thresholds=thr, gap=gap, time_bins=time_bins)
+    raster, norm = fe.spikes_from_db(torch.from_numpy(db).cuda(), want_norm=True)
+    raster, norm = raster.cpu().numpy(), norm.cpu().numpy()
+    assert raster.shape == (3, n_filters * redundancy, time_bins * n_thr)
+    for b in range(3):
+        n_ref = O.normalise_resize(np.maximum(db[b], db[b].max() - 80.0), time_bins)      # create_dataset.py:60-78
+        np.testing.assert_allclose(norm[b], n_ref, rtol=0, atol=1e-12)
+        r_ref = np.repeat(O.encode_hysteresis(norm[b], thr, gap), redundancy, axis=0)     # create_dataset.py:101-104
+        np.testing.assert_array_equal(raster[b], r_ref)
+
+
 def test_encoder_matches_reference_golden(torch_cuda, golden_dir):
     from lsm_speech_classifier_amd import frontend
     g = np.load(os.path.join(golden_dir, "encoder.npz"))
