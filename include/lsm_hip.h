@@ -120,8 +120,9 @@ int lsm_mel_power_f32(const float *audio, int n_clips, int n_samples, int n_fft,
  *                    its first n_clips*4 bytes (one counter per clip) must be ZERO on entry and are zero again when
  *                    the launch has finished (allocate once with zeros, reuse for ever -- stream-ordered launches only)
  *   raster           (n_clips, n_mels*redundancy, time_bins*n_thr) uint8
- * LSM_ERR_UNSUPPORTED when the clip's bit-packed raster stage (n_mels rows) exceeds the kernel's 32 KB of LDS
- * (more than ~600 filters at 4 thresholds x 100 bins): use the three split entry points. */
+ * LSM_ERR_UNSUPPORTED when the latch bit rows of the finishing workgroup (64 rows x n_thr x ceil(time_bins / 32) words, twice)
+ * exceed the kernel's 68 KB of LDS (more than ~1000 time bins at 4 thresholds; any number of filters fits): use the three
+ * split entry points. */
 long lsm_mel_spikes_workspace(int n_clips, int n_mels, int n_frames);
 int lsm_mel_spikes_f32(const float *audio, int n_clips, int n_samples, int n_fft, int hop, int n_frames,
                        const double *window_dev, const double *twiddle_dev, const float *basis_dev,

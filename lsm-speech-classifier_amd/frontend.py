@@ -253,7 +253,7 @@ class SpikeFrontEnd:
         """audio (B, n_samples) -> uint8 spike raster (B, C, n_steps) on the device.  The gammatone branch is one
         launch (`lsm_gammatone_spikes_f64`); `fused=False` takes the split entry points (identical rasters), which is
         also what the mel branch takes by default (its one-launch route, `fused=True` -> `lsm_mel_spikes_f32`, measured
-        slower) and what filterbanks too wide for the one-launch kernels use (`will_fuse()`).  `low_latency`: the
+        slower) and what shapes too large for the one-launch kernels use (`will_fuse()`).  `low_latency`: the
         fused launch in its one-chain layout (twice the waves, each half as long) -- for a batch that meets an idle
         GPU; `pipeline.HotPath` asks for it when none of its front ends is in flight.  `share_lds`: the launch runs
         beside LDS-hungry workgroups of another kernel (the ring-row reservoir kernel, two 64 KB clips per CU): it then
