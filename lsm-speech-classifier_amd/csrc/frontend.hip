@@ -151,8 +151,15 @@ __global__ __launch_bounds__(GT_MAX_WPB * 64) void gammatone_kernel(
 using lsm_fe::MAX_THR;
 using lsm_fe::SpikeArgs;
 
+#ifndef LSM_SPK_THREADS
+#define LSM_SPK_THREADS 256     // threads of a spec_to_spikes_kernel workgroup (one clip).  Alone on the GPU sixteen waves are faster than
+                                // four (21.5 against 32.7 us per 200 clips: with one wave per SIMD every dependent instruction waits out
+                                // its latency), inside the overlapped pipeline the small workgroup is (cfg1: 1.26-1.29 M clips/s with 256
+                                // threads, 1.22-1.26 M with 512, 1.13-1.15 M with 1024, which must find a whole CU's wave slots free;
+                                // profiles/r05_mel_wave_per_frame.txt)
+#endif
 template <typename T>
-__global__ __launch_bounds__(256) void spec_to_spikes_kernel(const SpikeArgs<T> a)
+__global__ __launch_bounds__(LSM_SPK_THREADS) void spec_to_spikes_kernel(const SpikeArgs<T> a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     lsm_fe::spec_to_spikes_body<T>(a, (int)blockIdx.x, smem);
@@ -588,7 +595,7 @@ int launch_spec_to_spikes(const T *db, int n_clips, int n_filters, int ncols, in
     LSM_REQUIRE(lds <= 160 * 1024, "latch bit rows of %zu bytes (time_bins x thresholds) exceed one CU's LDS", lds);
     auto fn = spec_to_spikes_kernel<T>;
     if (lds > 64 * 1024) lsm_allow_big_lds(reinterpret_cast<const void *>(fn));
-    hipLaunchKernelGGL(fn, dim3(n_clips), dim3(256), lds, (hipStream_t)stream, a);
+    hipLaunchKernelGGL(fn, dim3(n_clips), dim3(LSM_SPK_THREADS), lds, (hipStream_t)stream, a);
     LSM_CHECK_HIP(hipGetLastError());
     return LSM_OK;
 }

@@ -38,16 +38,19 @@ __device__ __forceinline__ T block_reduce(T v, bool is_max, T *scratch)
     return r;
 }
 
+#ifndef LSM_SPK_ABLATE
+#define LSM_SPK_ABLATE 0    // diagnostic builds only (WRONG results): 1 = no minimum/maximum pass, 2 = no values / comparison bits,
+#endif                      // 4 = no latches, 8 = no raster bytes (profiles/r05_mel_wave_per_frame.txt)
 constexpr int SPK_ROWS = 64;               // spectrogram rows (filters) a workgroup encodes at a time
 
-// LDS bytes of spec_to_spikes_body: 64 of reduction scratch + two bit arrays (value above the on-threshold / below the
+// LDS bytes of spec_to_spikes_body: 128 of reduction scratch (sixteen waves) + two bit arrays (value above the on-threshold / below the
 // off-threshold; the first becomes the latch state) of SPK_ROWS rows x n_thr thresholds x ceil(time_bins / 32) words
 __host__ __device__ inline size_t spikes_lds_bytes(int time_bins, int n_thr)
 {
-    return 64 + 2 * (size_t)SPK_ROWS * (size_t)(n_thr > 0 ? n_thr : 1) * (size_t)((time_bins + 31) / 32) * 4;
+    return 128 + 2 * (size_t)SPK_ROWS * (size_t)(n_thr > 0 ? n_thr : 1) * (size_t)((time_bins + 31) / 32) * 4;
 }
 
-// One 256-thread workgroup, one clip `b`: min/max, floor, normalise, SciPy-exact resize, hysteresis latches, raster.
+// One workgroup of 4 to 16 waves, one clip `b`: min/max, floor, normalise, SciPy-exact resize, hysteresis latches, raster.
 // `smem`: spikes_lds_bytes(time_bins, n_thr).  Shared by spec_to_spikes_kernel (frontend.hip) and the one-launch mel front
 // end (mel.hip), whose last workgroup of a clip runs it on the dB values it has just formed.
 // Three passes over groups of SPK_ROWS rows (round 5; before, ONE thread walked a row's time bins, its two loads per bin
@@ -60,10 +63,10 @@ __host__ __device__ inline size_t spikes_lds_bytes(int time_bins, int n_thr)
 template <typename T>
 __device__ __forceinline__ void spec_to_spikes_body(const SpikeArgs<T> &a, const int b, unsigned char *smem)
 {
-    T *scratch = reinterpret_cast<T *>(smem);                 // 8 entries
+    T *scratch = reinterpret_cast<T *>(smem);                 // 16 entries: one per wave of up to 1024 threads
     const int F = a.n_filters, nc = a.ncols, Tb = a.time_bins, nq = a.n_thr;
     const int W = (Tb + 31) >> 5;                             // words of a bit row
-    uint32_t *onb = reinterpret_cast<uint32_t *>(smem + 64);  // [row in group][q][W]: above on[q]; then the latch state
+    uint32_t *onb = reinterpret_cast<uint32_t *>(smem + 128); // [row in group][q][W]: above on[q]; then the latch state
     uint32_t *offb = onb + (size_t)SPK_ROWS * (nq > 0 ? nq : 1) * W;
     const T *db = a.db + (size_t)b * F * nc;
     const int n = F * nc;
@@ -72,7 +75,7 @@ __device__ __forceinline__ void spec_to_spikes_body(const SpikeArgs<T> &a, const
     T mx = -INFINITY, mn = INFINITY;
     int nan_seen = 0;
 #pragma unroll 8
-    for (int i = tid; i < n; i += blockDim.x) {
+    for (int i = tid; i < ((LSM_SPK_ABLATE & 1) ? 0 : n); i += blockDim.x) {
         const T v = db[i];
         mx = v > mx ? v : mx;
         mn = v < mn ? v : mn;
@@ -99,7 +102,7 @@ __device__ __forceinline__ void spec_to_spikes_body(const SpikeArgs<T> &a, const
         const int rows = min(SPK_ROWS, F - r0);
         // ---- 1. values and comparison bits: a wave takes (row, 64 time bins) pieces four at a time, their loads together ----
         const int nh = (Tb + 63) >> 6, npiece = rows * nh;
-        for (int p0 = wv; p0 < npiece; p0 += 4 * nwv) {
+        for (int p0 = wv; p0 < ((LSM_SPK_ABLATE & 2) ? 0 : npiece); p0 += 4 * nwv) {
             T x0[4], x1[4];
             double w0[4], w1[4];
             bool two[4];
@@ -163,7 +166,7 @@ __device__ __forceinline__ void spec_to_spikes_body(const SpikeArgs<T> &a, const
         __syncthreads();
         // ---- 2. the latches: where above and below exclude each other (off <= on), active' = above | (active & ~below) is the
         //      carry chain of an addition: generate = above, propagate = ~below, so a word of 32 time bins is one 64-bit add ----
-        for (int i = tid; i < rows * nq; i += blockDim.x) {
+        for (int i = tid; i < ((LSM_SPK_ABLATE & 4) ? 0 : rows * nq); i += blockDim.x) {
             uint32_t *o = onb + (size_t)i * W;
             const uint32_t *d = offb + (size_t)i * W;
             uint64_t active = 0u;
@@ -188,7 +191,7 @@ __device__ __forceinline__ void spec_to_spikes_body(const SpikeArgs<T> &a, const
         }
         __syncthreads();
         // ---- 3. raster bytes of the group's rows (create_pure_redundancy: output row c reads filter row c / redundancy) ----
-        if (dst) {
+        if (dst && !(LSM_SPK_ABLATE & 8)) {
             const int c0 = r0 * a.redundancy, nrow = rows * a.redundancy;
             if ((row_bytes & 3) == 0) {
                 const int rw = row_bytes / 4;

@@ -93,7 +93,7 @@ class MelSpectrogram:
     def fits_one_launch(self, time_bins: int, n_thr: int) -> bool:
         """The finishing workgroup keeps its latch bit rows (64 rows x thresholds x time-bin words, twice) in the four waves'
         point buffers (csrc/spikes_body.h: spikes_lds_bytes; csrc/mel.hip: 4 x 17 408 bytes)."""
-        return 64 + 2 * 64 * max(n_thr, 1) * ((time_bins + 31) // 32) * 4 <= 4 * 17408
+        return 128 + 2 * 64 * max(n_thr, 1) * ((time_bins + 31) // 32) * 4 <= 4 * 17408
 
     def spikes(self, audio: torch.Tensor, on: np.ndarray, off: np.ndarray, time_bins: int, redundancy: int,
                raster_out: torch.Tensor | None = None, workspace: torch.Tensor | None = None) -> torch.Tensor:
