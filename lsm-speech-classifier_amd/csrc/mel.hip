@@ -23,7 +23,6 @@ constexpr int NFFT = 2048;
 constexpr int N2 = NFFT / 2;                 // the real frame is transformed as N2 complex points
 constexpr int NBINS = NFFT / 2 + 1;
 constexpr int ZPAD = N2 + N2 / 16;           // a wave's point buffer: one pad element after every 16 (see zpad)
-constexpr int PWPAD = NBINS + 3;
 
 // W_2048^m for any m in [0, 2048) from the table of the first 1024 powers (W^(m+1024) = -W^m)
 __device__ __forceinline__ double2 tw2048(const double2 *__restrict__ t, int m)
@@ -101,7 +100,7 @@ struct MelArgs {
 // out) with strides p = 1 (radix 16, inputs straight from memory, no twiddles), p = 16 (radix 16) and p = 256 (radix 4, four
 // butterflies per lane): out[j + r p] = sum_q W_R^(q r) W_(R p)^(q k) in[i + q N/R], k = i mod p, j = (i - k) R + k.  Then
 // the 1025 bins of the real transform, X[k] = E[k] - i W^k O[k], E/O = (Z[k] +- conj Z[N2-k]) / 2.  All in float64.
-// `z`: this wave's ZPAD points of LDS; the power values reuse its first PWPAD floats.  (Twiddle products instead of table entries move the float64
+// `z`: this wave's ZPAD points of LDS; the power values reuse its first NBINS floats.  (Twiddle products instead of table entries move the float64
 // spectrum by a few 1e-16 relative: the table's own rounding.)
 __device__ __forceinline__ void mel_frame_wave(const MelArgs &a, double2 *z, const int b, const int t)
 {
