@@ -105,7 +105,8 @@ int lsm_spec_to_spikes_f32(const float *db, int n_clips, int n_filters, int ncol
  * create_dataset.py:44-47 (n_fft must be 2048, librosa's default): centred zero-padded frames,
  * float64 window x float32 frame, float64 FFT stored as complex64, |.|^2 in float32, mel basis.
  *   window_dev (n_fft) f64, twiddle_dev (n_fft/2, 2) f64 {cos, -sin}, basis_dev (n_mels, n_fft/2+1)
- *   f32, lo_dev/hi_dev (n_mels) i32 non-zero bin range of each filter: DEVICE tables built by the host
+ *   f32, lo_dev/hi_dev (n_mels) i32 non-zero bin range of each filter: DEVICE tables built by the host;
+ *   window_dev and twiddle_dev 16-byte aligned (the kernel fetches them two doubles at a time)
  *   power_out (n_clips, n_mels, n_frames) float32, n_frames = 1 + n_samples / hop */
 int lsm_mel_power_f32(const float *audio, int n_clips, int n_samples, int n_fft, int hop,
                       int n_frames, const double *window_dev, const double *twiddle_dev,

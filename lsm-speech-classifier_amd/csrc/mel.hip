@@ -352,6 +352,7 @@ LSM_API int lsm_mel_power_f32(const float *audio, int n_clips, int n_samples, in
     if (n_clips == 0) return LSM_OK;
     LSM_REQUIRE(audio && window_dev && twiddle_dev && basis_dev && lo_dev && hi_dev && power_out,
                 "mel: null buffer");
+    LSM_REQUIRE((((uintptr_t)window_dev | (uintptr_t)twiddle_dev) & 15u) == 0, "mel: window and twiddle tables must be 16-byte aligned");
     MelArgs a;
     a.audio = audio; a.n_samples = n_samples; a.hop = hop; a.n_frames = n_frames; a.n_mels = n_mels;
     a.window = window_dev; a.twiddle = reinterpret_cast<const double2 *>(twiddle_dev); a.basis = basis_dev;
@@ -383,6 +384,7 @@ LSM_API int lsm_mel_spikes_f32(const float *audio, int n_clips, int n_samples, i
     if (n_clips == 0) return LSM_OK;
     LSM_REQUIRE(audio && window_dev && twiddle_dev && basis_dev && lo_dev && hi_dev && raster && workspace,
                 "mel_spikes: null buffer");
+    LSM_REQUIRE((((uintptr_t)window_dev | (uintptr_t)twiddle_dev) & 15u) == 0, "mel_spikes: window and twiddle tables must be 16-byte aligned");
     LSM_REQUIRE(workspace_bytes >= lsm_mel_spikes_workspace(n_clips, n_mels, n_frames),
                 "workspace of %ld bytes, need %ld (lsm_mel_spikes_workspace)", workspace_bytes,
                 lsm_mel_spikes_workspace(n_clips, n_mels, n_frames));
