@@ -46,6 +46,31 @@ def test_mel_frontend_matches_oracle(n_mels):
     assert flips == 0                                    # (larger seeded set: test_mel_rasters_equal_the_oracle_exactly)
 
 
+@pytest.mark.parametrize("n_samples,time_bins", [(15999, 100), (8001, 100), (1500, 100), (4097, 37), (2048, 64), (333, 10)])
+def test_mel_power_over_clip_lengths(n_samples, time_bins):
+    """Clips whose length is odd, not a multiple of the hop, or SHORTER than the 2048-sample window (every frame then reaches
+    past both ends of the clip), odd hops: the frame's samples come from clamped indices and are dropped where the frame lies
+    outside the clip (csrc/mel.hip) -- against the oracle's zero-padded frames, power and dB within SPEC.md 1.5's tolerances,
+    both routes giving the same raster."""
+    import torch
+    from lsm_speech_classifier_amd import frontend, synth
+    from oracle import ref_numpy as O
+    full = synth.class_chirps([0, 3, 7], seed=n_samples)
+    audio = np.ascontiguousarray(full[:, :n_samples])
+    audio[2] = synth.white_noise(1, seed=n_samples + 1)[0, :n_samples]
+    fe = frontend.SpikeFrontEnd(24, "mel", time_bins=time_bins, n_samples=n_samples)
+    hop = max(1, int(n_samples / time_bins))
+    assert fe._mel.hop == hop and fe.ncols == 1 + n_samples // hop
+    power = fe._mel.power(torch.from_numpy(audio).cuda()).cpu().numpy()
+    db, _ = fe.spectrogram_db(audio)
+    for b in range(3):
+        p_ref = O.mel_power(audio[b], 24, hop=hop)
+        assert p_ref.shape == power[b].shape
+        np.testing.assert_allclose(power[b], p_ref, rtol=1e-5, atol=2e-6 * p_ref.max())
+        np.testing.assert_allclose(db[b].cpu().numpy(), O.power_to_db(p_ref), rtol=0, atol=1e-4)
+    assert torch.equal(fe.encode(audio, fused=False), fe.encode(audio, fused=True))
+
+
 @pytest.mark.parametrize("n_mels", [13, 40, 80, 128])
 def test_mel_rasters_equal_the_oracle_exactly(n_mels):
     """the mel branch's rasters are asserted EQUAL to the oracle's (create_dataset.py:43-48 + :62-98 through
